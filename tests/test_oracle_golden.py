@@ -1,0 +1,144 @@
+"""Pin the oracle (oracle/loss_chain.py) against vectors produced by the reference itself
+(tests/golden/make_golden.py imported vo/learner_func.py + vo/learner_new.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_chain_inputs, load_golden
+from oracle import loss_chain as O
+
+# fp32 tolerances: the oracle repeats the reference's op order, so most values agree to a few ulp;
+# matmul association / FMA contraction inside torch differs slightly -> 1e-6-level slack.
+ATOL, RTOL = 2e-6, 2e-5
+
+
+def close(a, b, atol=ATOL, rtol=RTOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def close_frac(a, b, atol, rtol, frac=2e-3, l2=2e-3):
+    """Gradients through min/argmin, the SSIM clamp and floor() are discontinuous: a rounding-level
+    change upstream flips a handful of pixels.  Require all but `frac` of the elements to agree
+    and the relative L2 error of the whole tensor to stay small."""
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    assert bad.mean() <= frac, "mismatch fraction %.2e" % bad.mean()
+    num = np.linalg.norm(np.where(bad, 0, a - b).astype(np.float64))   # flipped pixels excluded
+    den = np.linalg.norm(b.astype(np.float64)) + 1e-30
+    assert num / den < l2, "rel L2 %.3e" % (num / den)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return load_golden("ops_b2_48x64.npz")
+
+
+@pytest.mark.parametrize("inv", [False, True])
+def test_pose_to_matrix(ops, inv):
+    tag = "inv" if inv else "fwd"
+    aa = torch.from_numpy(ops["pose/aa"]).requires_grad_(True)
+    t = torch.from_numpy(ops["pose/t"]).requires_grad_(True)
+    M = O.transformation_from_parameters(aa, t, invert=inv)
+    close(M, ops["pose/%s/M" % tag])
+    (M * torch.from_numpy(ops["pose/cot"])).sum().backward()
+    close(aa.grad, ops["pose/%s/d_aa" % tag], atol=1e-5)
+    close(t.grad, ops["pose/%s/d_t" % tag], atol=1e-5)
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 3])
+def test_upsample_depth(ops, s):
+    d = torch.from_numpy(ops["up/%d/disp" % s]).requires_grad_(True)
+    H, W = ops["up/0/disp"].shape[2:]
+    up = O.upsample_bilinear(d, H, W)
+    close(up, ops["up/%d/disp_up" % s])
+    _, depth = O.disp_to_depth(up, 0.1, 10.0)
+    close(depth, ops["up/%d/depth" % s])
+    (depth * torch.from_numpy(ops["up/%d/cot" % s])).sum().backward()
+    close(d.grad, ops["up/%d/d_disp" % s], atol=1e-4, rtol=1e-4)
+
+
+def test_warp(ops):
+    depth = torch.from_numpy(ops["warp/depth"]).requires_grad_(True)
+    T = torch.from_numpy(ops["warp/T"]).requires_grad_(True)
+    K, inv_K = torch.from_numpy(ops["warp/K"]), torch.from_numpy(ops["warp/inv_K"])
+    H, W = depth.shape[2:]
+    cam = O.backproject(depth, inv_K)
+    close(cam, ops["warp/cam"])
+    grid = O.project(cam, K, T, H, W)
+    close(grid, ops["warp/grid"], atol=1e-5)
+    color = O.grid_sample_border(torch.from_numpy(ops["warp/src"]), grid)
+    close(color, ops["warp/color"], atol=2e-5)
+    (color * torch.from_numpy(ops["warp/cot"])).sum().backward()
+    close(depth.grad, ops["warp/d_depth"], atol=2e-3, rtol=2e-3)
+    close(T.grad, ops["warp/d_T"], atol=2e-2, rtol=2e-3)
+
+
+def test_grid_sample_border_edges(ops):
+    grid = torch.from_numpy(ops["gs/grid"]).requires_grad_(True)
+    col = O.grid_sample_border(torch.from_numpy(ops["warp/src"]), grid)
+    close(col, ops["gs/color"], atol=1e-5)
+    (col * torch.from_numpy(ops["warp/cot"])).sum().backward()
+    close(grid.grad, ops["gs/d_grid"], atol=2e-3, rtol=1e-3)
+    # outside the image the coordinate is clamped and its gradient must be exactly zero
+    out = (np.abs(ops["gs/grid"]) > 1).any(-1)
+    g = grid.grad.numpy()
+    assert out.any()
+    assert (g[..., 0][np.abs(ops["gs/grid"][..., 0]) > 1] == 0).all()
+    assert (g[..., 1][np.abs(ops["gs/grid"][..., 1]) > 1] == 0).all()
+
+
+def test_ssim_and_reprojection(ops):
+    pred = torch.from_numpy(ops["ssim/pred"]).requires_grad_(True)
+    tgt = torch.from_numpy(ops["ssim/target"])
+    s = O.ssim(pred, tgt)
+    close(s, ops["ssim/out"], atol=1e-5)
+    (s * torch.from_numpy(ops["ssim/cot"])).sum().backward()
+    close(pred.grad, ops["ssim/d_pred"], atol=2e-3, rtol=2e-3)
+    pred2 = torch.from_numpy(ops["ssim/pred"]).requires_grad_(True)
+    r = O.reprojection_loss(pred2, tgt)
+    close(r, ops["reproj/out"], atol=1e-5)
+    (r * torch.from_numpy(ops["reproj/cot"])).sum().backward()
+    close(pred2.grad, ops["reproj/d_pred"], atol=2e-3, rtol=2e-3)
+
+
+def test_smoothness(ops):
+    d = torch.from_numpy(ops["smooth/disp"]).requires_grad_(True)
+    img = torch.from_numpy(ops["smooth/img"])
+    mean_disp = torch.clamp(d.mean(2, True).mean(3, True), min=0.001)
+    sm = O.smooth_loss(d / (mean_disp + 1e-7), img)
+    close(sm, ops["smooth/out"], rtol=1e-5)
+    sm.backward()
+    close(d.grad, ops["smooth/d_disp"], atol=1e-7, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name", ["chain_b2_48x64.npz", "chain_b2_96x128.npz", "chain_b1_48x64_s1.npz"])
+def test_whole_chain(name):
+    rec = load_golden(name)
+    sample, disps, poses, noise, ns = golden_chain_inputs(rec)
+    outputs, losses, grads = O.loss_chain_with_grads(sample, disps, poses, noise, num_scales=ns)
+    close(losses["loss"], rec["loss"], rtol=1e-5)
+    for s in range(ns):
+        close(losses["loss/%d" % s], rec["loss/%d" % s], rtol=1e-5)
+        sel = outputs["identity_selection/%d" % s].numpy().astype(np.uint8)
+        assert (sel != rec["out/identity_selection%d" % s]).mean() < 1e-3
+        close_frac(grads["disp"][s], rec["grad/disp%d" % s], atol=2e-8, rtol=2e-3)
+        if "out/depth%d" % s in rec:
+            close(outputs[("depth", s)], rec["out/depth%d" % s])
+            for f, nm in ((-1, "m1"), (1, "p1")):
+                close(outputs[("color", f, s)], rec["out/color_%s_%d" % (nm, s)], atol=2e-5)
+                close(outputs[("sample", f, s)], rec["out/sample_%s_%d" % (nm, s)], atol=1e-5)
+    for i, n in enumerate(("aa_left", "t_left", "aa_right", "t_right")):
+        # pose grads sum over every pixel, flipped ones included -> percent-level sensitivity
+        close(grads["pose"][i], rec["grad/" + n], atol=1e-4, rtol=1e-2)
+    close(outputs[("cam_T_cam", 0, -1)], rec["out/T_m1"])
+    close(outputs[("cam_T_cam", 0, 1)], rec["out/T_p1"])
+
+
+def test_fp64_oracle_brackets_fp32():
+    """The float64 oracle and the reference's fp32 numbers agree to fp32 rounding: this is the
+    yardstick the GPU parity tolerances are derived from."""
+    rec = load_golden("chain_b2_48x64.npz")
+    sample, disps, poses, noise, ns = golden_chain_inputs(rec)
+    _, losses, grads = O.loss_chain_with_grads(sample, disps, poses, noise, dtype=torch.float64)
+    assert abs(float(losses["loss"]) - float(rec["loss"])) < 2e-6 * abs(float(rec["loss"])) + 1e-7
