@@ -1,0 +1,98 @@
+"""ctypes binding of libdvslam_hip.so (the C-ABI declared in include/dvslam.h).
+
+There is no fallback: `lib()` raises if the shared library has not been built, and every wrapper
+raises `DvsError` on a non-zero status.  torch must be imported before the library is loaded so
+that both share one HIP runtime (libamdhip64.so.7) and therefore one set of streams.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
+MAX_SCALES = 4
+ABI_VERSION = 1
+
+_vp = C.c_void_p
+
+
+class DvsError(RuntimeError):
+    pass
+
+
+class ChainCfg(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("num_scales", C.c_int),
+                ("hs", C.c_int * MAX_SCALES), ("ws", C.c_int * MAX_SCALES),
+                ("auto_mask", C.c_int), ("min_depth", C.c_float), ("max_depth", C.c_float),
+                ("ssim_ratio", C.c_float), ("smoothness_ratio", C.c_float)]
+
+
+class ChainFwdIO(C.Structure):
+    _fields_ = [("target", _vp), ("source", _vp * 2), ("disp", _vp * MAX_SCALES),
+                ("K", _vp), ("inv_K", _vp), ("T", _vp * 2), ("noise", _vp), ("seed", C.c_uint64),
+                ("partials", _vp), ("sel", _vp), ("stats", _vp), ("losses", _vp),
+                ("disp_up", _vp * MAX_SCALES), ("depth", _vp * MAX_SCALES),
+                ("grid", (_vp * 2) * MAX_SCALES), ("color", (_vp * 2) * MAX_SCALES)]
+
+
+class ChainBwdIO(C.Structure):
+    _fields_ = [("d_losses", _vp), ("d_disp", _vp * MAX_SCALES), ("d_T", _vp * 2),
+                ("bwd_partials", _vp)]
+
+
+_SIGNATURES = {
+    "dvs_last_error": (C.c_char_p, []),
+    "dvs_abi_version": (C.c_int, []),
+    "dvs_arch": (C.c_char_p, []),
+    "dvs_pose_to_mat_fwd": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "dvs_pose_to_mat_bwd": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
+    "dvs_chain_workspace": (C.c_int, [C.POINTER(ChainCfg)] + [C.POINTER(C.c_size_t)] * 4),
+    "dvs_chain_fwd": (C.c_int, [C.POINTER(ChainCfg), C.POINTER(ChainFwdIO), _vp]),
+    "dvs_chain_bwd": (C.c_int, [C.POINTER(ChainCfg), C.POINTER(ChainFwdIO), C.POINTER(ChainBwdIO), _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/dvslam.h declares (checked by tests/test_abi.py)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libdvslam_hip.so once; raise loudly if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DvsError("libdvslam_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` or `python -m deep_visual_slam_amd.build`." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.dvs_abi_version() != ABI_VERSION:
+            raise DvsError("libdvslam_hip.so ABI %d != binding ABI %d; rebuild" % (l.dvs_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DvsError("%s failed (%d): %s" % (what, rc, lib().dvs_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/u8 CUDA(HIP) tensor, or NULL for None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DvsError("libdvslam_hip operates on GPU tensors only (got %s); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise DvsError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,800 @@
+// a5-a12: the fused view-synthesis loss chain (forward + backward) for gfx950.
+//
+// One launch covers every scale and both source frames of a batch.  A 256-thread workgroup owns a
+// 64x16 pixel tile of one image: 64 lanes run along x so every row access is one coalesced 256-B
+// segment; the 3x3 SSIM window and the smoothness stencil are served from LDS tiles that carry a
+// reflect-padded halo (1 px forward, 2 px backward).  Warped colours are never written to HBM
+// unless the caller asks for the reference's `outputs` tensors; the backward recomputes them.
+// Reductions: wavefront butterfly (64 lanes) -> LDS -> one partial row per workgroup -> a small
+// finalize kernel (deterministic, no float atomics on the loss).
+//
+// Reference arithmetic restated here (file:line under the reference repo):
+//   F.interpolate bilinear/align_corners=False   vo/learner_new.py:136-140
+//   disp_to_depth                                vo/learner_func.py:16-26
+//   BackprojectDepth / Project3D                 vo/learner_func.py:106-159
+//   F.grid_sample border / align_corners=True    vo/learner_new.py:165-170
+//   SSIM, reprojection loss                      vo/learner_func.py:177-207, vo/learner_new.py:60-74
+//   auto-mask min, smoothness, loss assembly     vo/learner_new.py:199-257
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 64, TH = 16, NT = 256, PX = 4;  // tile, threads, pixels per thread
+constexpr int FH = TH + 2, FW = TW + 2;            // forward tile + 1-px halo
+constexpr int BH = TH + 4, BW = TW + 4;            // backward tile + 2-px halo
+constexpr int ACC_W = TW / 2 + 4, ACC_H = TH / 2 + 4;  // low-res d_disp footprint of a tile (ratio >= 2)
+constexpr int NPART = 16;                          // forward partial row: 4 scales x {min, sum disp, Gx, Gy}
+constexpr int NDP = 12;                            // dP = d loss / d (K.T)[:3,:4]
+constexpr float C1 = 0.0001f, C2 = 0.0009f;        // SSIM constants, learner_func.py:190-191
+
+struct ChainParams {
+    dvs_chain_cfg cfg;
+    dvs_chain_fwd_io io;
+    int tiles_x, tiles_y;
+};
+
+struct CamMats {
+    float iK[9];   // inv_K[:3,:3]
+    float P[12];   // (K @ T)[:3,:]
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+__device__ __forceinline__ void load_cam(const ChainParams& p, int b, int f, CamMats& m) {
+    const float* K = p.io.K + b * 16;
+    const float* T = p.io.T[f] + b * 16;
+    const float* iK = p.io.inv_K + b * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float acc = K[i * 4 + 0] * T[0 * 4 + j];
+            acc = fmaf(K[i * 4 + 1], T[1 * 4 + j], acc);
+            acc = fmaf(K[i * 4 + 2], T[2 * 4 + j], acc);
+            acc = fmaf(K[i * 4 + 3], T[3 * 4 + j], acc);
+            m.P[i * 4 + j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m.iK[i * 3 + j] = iK[i * 4 + j];
+    }
+}
+
+// Bilinear upsample of a [hs,ws] disparity map to (X,Y) of the [H,W] image, align_corners=False.
+__device__ __forceinline__ float disp_up_at(const float* __restrict__ d, int hs, int ws, int H, int W,
+                                            int X, int Y, float ry, float rx) {
+    if (hs == H && ws == W) return d[Y * W + X];
+    float sy = fmaxf(ry * (Y + 0.5f) - 0.5f, 0.f);
+    float sx = fmaxf(rx * (X + 0.5f) - 0.5f, 0.f);
+    int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
+    int y1 = y0 + (y0 < hs - 1), x1 = x0 + (x0 < ws - 1);
+    float ly = sy - y0, lx = sx - x0;
+    float v00 = d[y0 * ws + x0], v01 = d[y0 * ws + x1];
+    float v10 = d[y1 * ws + x0], v11 = d[y1 * ws + x1];
+    return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+}
+
+struct Warp {
+    float depth, c0, c1, c2;      // depth and the pixel ray inv_K.[X,Y,1]
+    float den, u, v;              // projective divide
+    float gx, gy;                 // normalised grid (Project3D output)
+    float ix, iy;                 // clipped source coordinate
+    float mx, my;                 // 1 where the coordinate was NOT clipped (gradient passes)
+    int x0, y0;
+    float tx, ty;
+    bool in_x1, in_y1;
+};
+
+// BackprojectDepth -> Project3D -> grid_sample coordinate, with the reference's operation order.
+__device__ __forceinline__ void warp_geom(const CamMats& m, int X, int Y, float disp_up, float min_disp,
+                                          float disp_range, int H, int W, Warp& w) {
+    float scaled = min_disp + disp_range * disp_up;
+    w.depth = 1.0f / scaled;
+    float fx = (float)X, fy = (float)Y;
+    w.c0 = fmaf(m.iK[2], 1.f, fmaf(m.iK[1], fy, m.iK[0] * fx));
+    w.c1 = fmaf(m.iK[5], 1.f, fmaf(m.iK[4], fy, m.iK[3] * fx));
+    w.c2 = fmaf(m.iK[8], 1.f, fmaf(m.iK[7], fy, m.iK[6] * fx));
+    float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
+    float p0 = fmaf(m.P[3], 1.f, fmaf(m.P[2], Z3, fmaf(m.P[1], Y3, m.P[0] * X3)));
+    float p1 = fmaf(m.P[7], 1.f, fmaf(m.P[6], Z3, fmaf(m.P[5], Y3, m.P[4] * X3)));
+    float p2 = fmaf(m.P[11], 1.f, fmaf(m.P[10], Z3, fmaf(m.P[9], Y3, m.P[8] * X3)));
+    w.den = p2 + 1e-7f;
+    w.u = p0 / w.den;
+    w.v = p1 / w.den;
+    w.gx = (w.u / (float)(W - 1) - 0.5f) * 2.f;
+    w.gy = (w.v / (float)(H - 1) - 0.5f) * 2.f;
+    float ix = ((w.gx + 1.f) * 0.5f) * (float)(W - 1);
+    float iy = ((w.gy + 1.f) * 0.5f) * (float)(H - 1);
+    w.mx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f;
+    w.my = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    w.ix = ix;
+    w.iy = iy;
+    float x0f = floorf(ix), y0f = floorf(iy);
+    w.x0 = (int)x0f;
+    w.y0 = (int)y0f;
+    w.tx = ix - x0f;
+    w.ty = iy - y0f;
+    w.in_x1 = (w.x0 + 1) <= W - 1;
+    w.in_y1 = (w.y0 + 1) <= H - 1;
+}
+
+// Gather the 4 neighbours of one channel plane (out-of-range upper neighbours contribute 0).
+__device__ __forceinline__ void gather4(const float* __restrict__ plane, int W, const Warp& w, float& nw,
+                                        float& ne, float& sw, float& se) {
+    const float* r0 = plane + w.y0 * W + w.x0;
+    int dx = w.in_x1 ? 1 : 0;
+    int dy = w.in_y1 ? W : 0;
+    nw = r0[0];
+    ne = w.in_x1 ? r0[dx] : 0.f;
+    sw = w.in_y1 ? r0[dy] : 0.f;
+    se = (w.in_x1 && w.in_y1) ? r0[dy + dx] : 0.f;
+}
+
+__device__ __forceinline__ float bilerp(const Warp& w, float nw, float ne, float sw, float se) {
+    float wx1 = w.tx, wx0 = 1.f - w.tx, wy1 = w.ty, wy0 = 1.f - w.ty;
+    return nw * (wx0 * wy0) + ne * (wx1 * wy0) + sw * (wx0 * wy1) + se * (wx1 * wy1);
+}
+
+// SSIM statistics of one channel at window origin (ly,lx) of two LDS tiles with row stride `ld`.
+struct Stats {
+    float mux, muy, sigx, sigy, sigxy;
+};
+__device__ __forceinline__ Stats ssim_stats(const float* __restrict__ x, const float* __restrict__ y, int ld) {
+    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            float a = x[dy * ld + dx], b = y[dy * ld + dx];
+            sx += a;
+            sy += b;
+            sxx += a * a;
+            syy += b * b;
+            sxy += a * b;
+        }
+    }
+    Stats s;
+    s.mux = sx / 9.f;
+    s.muy = sy / 9.f;
+    s.sigx = sxx / 9.f - s.mux * s.mux;
+    s.sigy = syy / 9.f - s.muy * s.muy;
+    s.sigxy = sxy / 9.f - s.mux * s.muy;
+    return s;
+}
+
+__device__ __forceinline__ float ssim_value(const Stats& s) {
+    float n = (2.f * s.mux * s.muy + C1) * (2.f * s.sigxy + C2);
+    float d = (s.mux * s.mux + s.muy * s.muy + C1) * (s.sigx + s.sigy + C2);
+    return (1.f - n / d) * 0.5f;
+}
+
+// ssim_ratio * mean_c SSIM + (1 - ssim_ratio) * mean_c |t - p| at the pixel whose 3x3 window starts at
+// (ly,lx) of the halo tiles (learner_new.py:60-74).
+template <int LD, int PLANE>
+__device__ __forceinline__ float reproj_at(const float* __restrict__ sX, const float* __restrict__ sT, int ly,
+                                           int lx, float ssim_ratio) {
+    float ssim_sum = 0.f, l1_sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* x = sX + c * PLANE + ly * LD + lx;
+        const float* y = sT + c * PLANE + ly * LD + lx;
+        Stats st = ssim_stats(x, y, LD);
+        float v = ssim_value(st);
+        ssim_sum += fminf(fmaxf(v, 0.f), 1.f);
+        l1_sum += fabsf(y[LD + 1] - x[LD + 1]);
+    }
+    return ssim_ratio * (ssim_sum / 3.f) + (1.f - ssim_ratio) * (l1_sum / 3.f);
+}
+
+// ------------------------------------------------------------------------------ counter-based noise
+// Philox4x32-10 (Salmon et al.); stands in for the reference's torch.randn tie-break noise
+// (learner_new.py:226-229) when the caller does not inject a noise tensor.
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;  // (0,1)
+    float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
+    float r = sqrtf(-2.f * __logf(u1));
+    float s, c;
+    __sincosf(6.283185307179586f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// ------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
+    __shared__ float sT[3 * FH * FW];
+    __shared__ float sX[3 * FH * FW];
+    __shared__ float sD[FH * FW];
+    __shared__ float sRed[NT / 64][NPART];
+
+    const dvs_chain_cfg& c = p.cfg;
+    const int H = c.H, W = c.W, HW = H * W, S = c.num_scales;
+    const int b = blockIdx.z, X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const float min_disp = 1.0f / c.max_depth, disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
+    constexpr int PL = FH * FW;
+
+    const float* tgt = p.io.target + (size_t)b * 3 * HW;
+    for (int i = tid; i < PL; i += NT) {
+        int hy = i / FW, hx = i - hy * FW;
+        int gx = reflect_idx(X0 - 1 + hx, W), gy = reflect_idx(Y0 - 1 + hy, H);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) sT[ch * PL + i] = tgt[ch * HW + gy * W + gx];
+    }
+
+    float ident[2][PX];
+    if (c.auto_mask) {
+        for (int f = 0; f < 2; ++f) {
+            const float* src = p.io.source[f] + (size_t)b * 3 * HW;
+            for (int i = tid; i < PL; i += NT) {
+                int hy = i / FW, hx = i - hy * FW;
+                int gx = reflect_idx(X0 - 1 + hx, W), gy = reflect_idx(Y0 - 1 + hy, H);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) sX[ch * PL + i] = src[ch * HW + gy * W + gx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PX; ++k) ident[f][k] = reproj_at<FW, PL>(sX, sT, ty + 4 * k, tx, c.ssim_ratio);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+
+    float acc[DVS_MAX_SCALES][4];
+#pragma unroll
+    for (int s = 0; s < DVS_MAX_SCALES; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
+    uint32_t selbits[PX] = {0, 0, 0, 0};
+
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const int hs = c.hs[s], ws = c.ws[s];
+        const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
+        const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
+        float rp[2][PX];
+#pragma unroll 1
+        for (int f = 0; f < 2; ++f) {
+            CamMats m;
+            load_cam(p, b, f, m);
+            const float* src = p.io.source[f] + (size_t)b * 3 * HW;
+            for (int i = tid; i < PL; i += NT) {
+                int hy = i / FW, hx = i - hy * FW;
+                int px = X0 - 1 + hx, py = Y0 - 1 + hy;
+                int gx = reflect_idx(px, W), gy = reflect_idx(py, H);
+                float du = disp_up_at(dsp, hs, ws, H, W, gx, gy, ry, rx);
+                if (f == 0) sD[i] = du;
+                Warp w;
+                warp_geom(m, gx, gy, du, min_disp, disp_range, H, W, w);
+                float col[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float nw, ne, sw, se;
+                    gather4(src + ch * HW, W, w, nw, ne, sw, se);
+                    col[ch] = bilerp(w, nw, ne, sw, se);
+                    sX[ch * PL + i] = col[ch];
+                }
+                // optional materialisation of the reference's `outputs` tensors (interior pixels only)
+                bool interior = hx >= 1 && hx <= TW && hy >= 1 && hy <= TH && px < W && py < H;
+                if (interior) {
+                    size_t o = (size_t)b * HW + (size_t)py * W + px;
+                    if (p.io.color[s][f]) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch)
+                            p.io.color[s][f][(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)py * W + px] = col[ch];
+                    }
+                    if (p.io.grid[s][f]) {
+                        p.io.grid[s][f][o * 2 + 0] = w.gx;
+                        p.io.grid[s][f][o * 2 + 1] = w.gy;
+                    }
+                    if (f == 0) {
+                        if (p.io.disp_up[s]) p.io.disp_up[s][o] = du;
+                        if (p.io.depth[s]) p.io.depth[s][o] = w.depth;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PX; ++k) rp[f][k] = reproj_at<FW, PL>(sX, sT, ty + 4 * k, tx, c.ssim_ratio);
+            __syncthreads();
+        }
+
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            int X = X0 + tx, Y = Y0 + ty + 4 * k;
+            if (X >= W || Y >= H) continue;
+            // 4-way min with first-minimum-wins ties; candidates 0,1 = identity(-1,+1), 2,3 = reprojection(-1,+1)
+            float best = rp[0][k];
+            uint32_t idx = 2;
+            if (c.auto_mask) {
+                float n0, n1;
+                if (p.io.noise) {
+                    const float* nz = p.io.noise + ((size_t)s * c.B + b) * 2 * HW + (size_t)Y * W + X;
+                    n0 = nz[0];
+                    n1 = nz[HW];
+                } else {
+                    uint32_t r[4];
+                    philox4x32((uint32_t)(Y * W + X), (uint32_t)b, (uint32_t)(s >> 1), 0u,
+                               (uint32_t)p.io.seed, (uint32_t)(p.io.seed >> 32), r);
+                    if (s & 1) box_muller(r[2], r[3], n0, n1);
+                    else box_muller(r[0], r[1], n0, n1);
+                }
+                float i0 = ident[0][k] + n0 * 0.00001f, i1 = ident[1][k] + n1 * 0.00001f;
+                best = i0;
+                idx = 0;
+                if (i1 < best) { best = i1; idx = 1; }
+                if (rp[0][k] < best) { best = rp[0][k]; idx = 2; }
+            }
+            if (rp[1][k] < best) { best = rp[1][k]; idx = 3; }
+            acc[s][0] += best;
+            selbits[k] |= idx << (2 * s);
+
+            // smoothness partial sums on the un-normalised disparity (the per-image mean divides out
+            // in the finalize kernel): learner_new.py:246-250, learner_func.py:161-174
+            int ly = ty + 4 * k + 1, lx = tx + 1;
+            float d0 = sD[ly * FW + lx];
+            acc[s][1] += d0;
+            if (X < W - 1) {
+                float gi = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) gi += fabsf(sT[ch * PL + ly * FW + lx] - sT[ch * PL + ly * FW + lx + 1]);
+                acc[s][2] += fabsf(d0 - sD[ly * FW + lx + 1]) * __expf(-gi / 3.f);
+            }
+            if (Y < H - 1) {
+                float gi = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) gi += fabsf(sT[ch * PL + ly * FW + lx] - sT[ch * PL + (ly + 1) * FW + lx]);
+                acc[s][3] += fabsf(d0 - sD[(ly + 1) * FW + lx]) * __expf(-gi / 3.f);
+            }
+        }
+        __syncthreads();  // sD / sX are rewritten by the next scale
+    }
+
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        int X = X0 + tx, Y = Y0 + ty + 4 * k;
+        if (X < W && Y < H) p.io.sel[(size_t)b * HW + (size_t)Y * W + X] = (uint8_t)selbits[k];
+    }
+
+    // workgroup reduction: wave butterfly -> LDS -> 16 lanes
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int s = 0; s < DVS_MAX_SCALES; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = dvs::wave_sum(acc[s][j]);
+            if (lane == 0) sRed[wave][s * 4 + j] = v;
+        }
+    __syncthreads();
+    if (tid < NPART) {
+        float v = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+        int tile = blockIdx.y * p.tiles_x + blockIdx.x;
+        p.io.partials[((size_t)b * p.tiles_x * p.tiles_y + tile) * NPART + tid] = v;
+    }
+}
+
+// Stage 1: per image, sum the tile partials -> stats[b][s] = {sum min-loss, sum disp_up, Gx, Gy}.
+__global__ __launch_bounds__(NT) void chain_fwd_reduce_kernel(ChainParams p) {
+    __shared__ float sRed[NT / 64][NPART];
+    const int b = blockIdx.x, ntiles = p.tiles_x * p.tiles_y, tid = threadIdx.x;
+    // thread t handles column (t & 15) of rows (t >> 4), (t >> 4) + 16, ...
+    const int col = tid & 15;
+    float v = 0.f;
+    for (int r = tid >> 4; r < ntiles; r += NT / 16) v += p.io.partials[((size_t)b * ntiles + r) * NPART + col];
+    // lanes with equal `col` inside a wave: xor-reduce over lane bits 4,5
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if ((tid & 63) < 16) sRed[tid >> 6][col] = v;
+    __syncthreads();
+    if (tid < NPART) {
+        float t = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+        int s = tid >> 2, j = tid & 3;
+        if (s < p.cfg.num_scales) p.io.stats[((size_t)b * p.cfg.num_scales + s) * 4 + j] = t;
+    }
+}
+
+// Stage 2: losses[s] = mean(min) + ratio/2^s * (mean_x + mean_y) of the normalised smoothness terms.
+__global__ void chain_fwd_losses_kernel(ChainParams p) {
+    const dvs_chain_cfg& c = p.cfg;
+    int s = threadIdx.x;
+    if (s >= c.num_scales) return;
+    float minsum = 0.f, gx = 0.f, gy = 0.f;
+    float hw = (float)c.H * (float)c.W;
+    for (int b = 0; b < c.B; ++b) {
+        const float* st = p.io.stats + ((size_t)b * c.num_scales + s) * 4;
+        float mean = fmaxf(st[1] / hw, 0.001f) + 1e-7f;
+        minsum += st[0];
+        gx += st[2] / mean;
+        gy += st[3] / mean;
+    }
+    float nx = (float)c.B * (float)c.H * (float)(c.W - 1), ny = (float)c.B * (float)(c.H - 1) * (float)c.W;
+    float smooth = gx / nx + gy / ny;
+    p.io.losses[s] = minsum / ((float)c.B * hw) + c.smoothness_ratio * smooth / (float)(1 << s);
+}
+
+// ------------------------------------------------------------------------------------ backward
+struct BwdParams {
+    dvs_chain_bwd_io g;
+};
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams q) {
+    __shared__ float sT[3 * BH * BW];
+    __shared__ float sX[3 * BH * BW];
+    __shared__ float sD[BH * BW];
+    __shared__ float sF[3 * FH * FW];
+    __shared__ uint8_t sSel[FH * FW];
+    __shared__ float sAcc[ACC_H * ACC_W];
+    __shared__ float sRed[NT / 64][NDP];
+
+    const dvs_chain_cfg& c = p.cfg;
+    const int H = c.H, W = c.W, HW = H * W, S = c.num_scales;
+    const int b = blockIdx.z, X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
+    const float min_disp = 1.0f / c.max_depth, disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
+    constexpr int PLB = BH * BW, PLF = FH * FW;
+    const int tile = blockIdx.y * p.tiles_x + blockIdx.x, ntiles = p.tiles_x * p.tiles_y;
+
+    const float* tgt = p.io.target + (size_t)b * 3 * HW;
+    for (int i = tid; i < PLB; i += NT) {
+        int hy = i / BW, hx = i - hy * BW;
+        int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) sT[ch * PLB + i] = tgt[ch * HW + gy * W + gx];
+    }
+    for (int i = tid; i < PLF; i += NT) {
+        int hy = i / FW, hx = i - hy * FW;
+        int px = X0 - 1 + hx, py = Y0 - 1 + hy;
+        bool in = px >= 0 && px < W && py >= 0 && py < H;
+        sSel[i] = in ? p.io.sel[(size_t)b * HW + (size_t)py * W + px] : (uint8_t)0;
+    }
+    __syncthreads();
+
+    const float w_pix = 1.0f / ((float)c.B * (float)HW);
+    const float cx = 1.0f / ((float)c.B * (float)H * (float)(W - 1));
+    const float cy = 1.0f / ((float)c.B * (float)(H - 1) * (float)W);
+
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const int hs = c.hs[s], ws = c.ws[s];
+        const bool same_res = (hs == H && ws == W);
+        const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
+        const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
+        const float gl = q.g.d_losses[s];
+        const float w_ssim = gl * w_pix * c.ssim_ratio / 3.f * (-0.5f) / 9.f;
+        const float w_l1 = gl * w_pix * (1.f - c.ssim_ratio) / 3.f;
+        float gd[PX] = {0.f, 0.f, 0.f, 0.f};  // d loss / d disp_up at my pixels
+
+        for (int i = tid; i < ACC_H * ACC_W; i += NT) sAcc[i] = 0.f;
+
+#pragma unroll 1
+        for (int f = 0; f < 2; ++f) {
+            CamMats m;
+            load_cam(p, b, f, m);
+            const float* src = p.io.source[f] + (size_t)b * 3 * HW;
+            const uint32_t want = 2u + (uint32_t)f;
+            for (int i = tid; i < PLB; i += NT) {
+                int hy = i / BW, hx = i - hy * BW;
+                int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
+                float du = disp_up_at(dsp, hs, ws, H, W, gx, gy, ry, rx);
+                if (f == 0) sD[i] = du;
+                Warp w;
+                warp_geom(m, gx, gy, du, min_disp, disp_range, H, W, w);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float nw, ne, sw, se;
+                    gather4(src + ch * HW, W, w, nw, ne, sw, se);
+                    sX[ch * PLB + i] = bilerp(w, nw, ne, sw, se);
+                }
+            }
+            __syncthreads();
+
+            float dcol[PX][3];
+#pragma unroll
+            for (int k = 0; k < PX; ++k) dcol[k][0] = dcol[k][1] = dcol[k][2] = 0.f;
+
+#pragma unroll 1
+            for (int ch = 0; ch < 3; ++ch) {
+                // SSIM derivative coefficient fields at every pixel p of tile + 1-px halo:
+                // d out / d x(r) = -1/2 * 1/9 * (alpha(p) + beta(p) x(r) + gamma(p) y(r)) for r in window(p)
+                for (int i = tid; i < PLF; i += NT) {
+                    int hy = i / FW, hx = i - hy * FW;
+                    int px = X0 - 1 + hx, py = Y0 - 1 + hy;
+                    float fa = 0.f, fb = 0.f, fc = 0.f;
+                    bool in = px >= 0 && px < W && py >= 0 && py < H;
+                    if (in && ((sSel[i] >> (2 * s)) & 3u) == want) {
+                        Stats st = ssim_stats(sX + ch * PLB + hy * BW + hx, sT + ch * PLB + hy * BW + hx, BW);
+                        float n1 = 2.f * st.mux * st.muy + C1, n2 = 2.f * st.sigxy + C2;
+                        float d1 = st.mux * st.mux + st.muy * st.muy + C1, d2 = st.sigx + st.sigy + C2;
+                        float d = d1 * d2, R = (n1 * n2) / d;
+                        float v = (1.f - R) * 0.5f;
+                        if (v >= 0.f && v <= 1.f) {
+                            float dR_dmux = 2.f * st.muy * n2 / d - R * 2.f * st.mux / d1;
+                            float dR_dsx = -R / d2;
+                            float dR_dsxy = 2.f * n1 / d;
+                            fa = w_ssim * (dR_dmux - 2.f * st.mux * dR_dsx - st.muy * dR_dsxy);
+                            fb = w_ssim * 2.f * dR_dsx;
+                            fc = w_ssim * dR_dsxy;
+                        }
+                    }
+                    sF[0 * PLF + i] = fa;
+                    sF[1 * PLF + i] = fb;
+                    sF[2 * PLF + i] = fc;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                    if (X >= W || Y >= H) continue;
+                    int ly = ty + 4 * k + 1, lx = tx + 1;  // position in the 1-halo field tile
+                    float Sa = 0.f, Sb = 0.f, Sc = 0.f;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        // ReflectionPad2d(1): the window of border pixel 0 (H-1) reads row 1 (H-2) twice
+                        float wy = 1.f + ((Y == 1 && dy == -1) ? 1.f : 0.f) + ((Y == H - 2 && dy == 1) ? 1.f : 0.f);
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            float wx = 1.f + ((X == 1 && dx == -1) ? 1.f : 0.f) + ((X == W - 2 && dx == 1) ? 1.f : 0.f);
+                            int o = (ly + dy) * FW + lx + dx;
+                            float ww = wx * wy;
+                            Sa += ww * sF[0 * PLF + o];
+                            Sb += ww * sF[1 * PLF + o];
+                            Sc += ww * sF[2 * PLF + o];
+                        }
+                    }
+                    float xq = sX[ch * PLB + (ly + 1) * BW + lx + 1], yq = sT[ch * PLB + (ly + 1) * BW + lx + 1];
+                    float g = Sa + Sb * xq + Sc * yq;
+                    if (((sSel[ly * FW + lx] >> (2 * s)) & 3u) == want) g += w_l1 * sgn(xq - yq);
+                    dcol[k][ch] = g;
+                }
+                __syncthreads();
+            }
+
+            // chain d colour -> grid_sample -> projection -> depth -> disp_up, and dP = d/d (K.T)[:3,:]
+            float dP[NDP];
+#pragma unroll
+            for (int j = 0; j < NDP; ++j) dP[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                if (X >= W || Y >= H) continue;
+                float du = sD[(ty + 4 * k + 2) * BW + tx + 2];
+                Warp w;
+                warp_geom(m, X, Y, du, min_disp, disp_range, H, W, w);
+                float gix = 0.f, giy = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    float nw, ne, sw, se;
+                    gather4(src + ch * HW, W, w, nw, ne, sw, se);
+                    float go = dcol[k][ch];
+                    gix += go * ((ne - nw) * (1.f - w.ty) + (se - sw) * w.ty);
+                    giy += go * ((sw - nw) * (1.f - w.tx) + (se - ne) * w.tx);
+                }
+                // d ix / d u = mask (the (W-1)/2 and 2/(W-1) factors of unnormalise/normalise cancel)
+                float d_u = gix * w.mx, d_v = giy * w.my;
+                float dp0 = d_u / w.den, dp1 = d_v / w.den;
+                float dp2 = -(d_u * w.u + d_v * w.v) / w.den;
+                float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
+                dP[0] += dp0 * X3; dP[1] += dp0 * Y3; dP[2] += dp0 * Z3; dP[3] += dp0;
+                dP[4] += dp1 * X3; dP[5] += dp1 * Y3; dP[6] += dp1 * Z3; dP[7] += dp1;
+                dP[8] += dp2 * X3; dP[9] += dp2 * Y3; dP[10] += dp2 * Z3; dP[11] += dp2;
+                float dc0 = m.P[0] * dp0 + m.P[4] * dp1 + m.P[8] * dp2;
+                float dc1 = m.P[1] * dp0 + m.P[5] * dp1 + m.P[9] * dp2;
+                float dc2 = m.P[2] * dp0 + m.P[6] * dp1 + m.P[10] * dp2;
+                float d_depth = dc0 * w.c0 + dc1 * w.c1 + dc2 * w.c2;
+                gd[k] += d_depth * (-w.depth * w.depth * disp_range);
+            }
+#pragma unroll
+            for (int j = 0; j < NDP; ++j) {
+                float v = dvs::wave_sum(dP[j]);
+                if (lane == 0) sRed[wave][j] = v;
+            }
+            __syncthreads();
+            if (tid < NDP) {
+                float v = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+                q.g.bwd_partials[((((size_t)b * ntiles + tile) * S + s) * 2 + f) * NDP + tid] = v;
+            }
+            __syncthreads();  // sX, sF, sRed reused by the next frame
+        }
+
+        // smoothness gradient (learner_new.py:246-252): loss_s += ratio/2^s * sum_b (Gx_b cx + Gy_b cy) / (m_b + eps)
+        {
+            const float* st = p.io.stats + ((size_t)b * S + s) * 4;
+            float hw = (float)HW;
+            float mean_raw = st[1] / hw;
+            float mean = fmaxf(mean_raw, 0.001f) + 1e-7f;
+            float gs = gl * c.smoothness_ratio / (float)(1 << s);
+            float k_grad = gs / mean;
+            float k_mean = (mean_raw >= 0.001f) ? -gs * (cx * st[2] + cy * st[3]) / (mean * mean) / hw : 0.f;
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                if (X >= W || Y >= H) continue;
+                int ly = ty + 4 * k + 2, lx = tx + 2;
+                float d0 = sD[ly * BW + lx];
+                float g = 0.f;
+                auto img_w = [&](int oy0, int ox0, int oy1, int ox1) {
+                    float gi = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        gi += fabsf(sT[ch * PLB + (ly + oy0) * BW + lx + ox0] - sT[ch * PLB + (ly + oy1) * BW + lx + ox1]);
+                    return __expf(-gi / 3.f);
+                };
+                if (X < W - 1) g += cx * sgn(d0 - sD[ly * BW + lx + 1]) * img_w(0, 0, 0, 1);
+                if (X > 0) g -= cx * sgn(sD[ly * BW + lx - 1] - d0) * img_w(0, -1, 0, 0);
+                if (Y < H - 1) g += cy * sgn(d0 - sD[(ly + 1) * BW + lx]) * img_w(0, 0, 1, 0);
+                if (Y > 0) g -= cy * sgn(sD[(ly - 1) * BW + lx] - d0) * img_w(-1, 0, 0, 0);
+                gd[k] += k_grad * g + k_mean;
+            }
+        }
+
+        // transpose of the bilinear upsample: d disp_up -> d disp_s
+        float* dd = q.g.d_disp[s] + (size_t)b * hs * ws;
+        if (same_res) {
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                if (X < W && Y < H) dd[Y * W + X] = gd[k];
+            }
+        } else {
+            // low-res footprint origin of this tile
+            int ox = max((int)fmaxf(rx * (X0 + 0.5f) - 0.5f, 0.f), 0), oy = max((int)fmaxf(ry * (Y0 + 0.5f) - 0.5f, 0.f), 0);
+            __syncthreads();  // sAcc zero-fill visible
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                if (X >= W || Y >= H) continue;
+                float sy = fmaxf(ry * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(rx * (X + 0.5f) - 0.5f, 0.f);
+                int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
+                int y1 = y0 + (y0 < hs - 1), x1 = x0 + (x0 < ws - 1);
+                float ly = sy - y0, lx = sx - x0;
+                float g = gd[k];
+                atomicAdd(&sAcc[(y0 - oy) * ACC_W + (x0 - ox)], g * (1.f - ly) * (1.f - lx));
+                atomicAdd(&sAcc[(y0 - oy) * ACC_W + (x1 - ox)], g * (1.f - ly) * lx);
+                atomicAdd(&sAcc[(y1 - oy) * ACC_W + (x0 - ox)], g * ly * (1.f - lx));
+                atomicAdd(&sAcc[(y1 - oy) * ACC_W + (x1 - ox)], g * ly * lx);
+            }
+            __syncthreads();
+            for (int i = tid; i < ACC_H * ACC_W; i += NT) {
+                int ay = i / ACC_W, ax = i - ay * ACC_W;
+                float v = sAcc[i];
+                int yy = oy + ay, xx = ox + ax;
+                if (v != 0.f && yy < hs && xx < ws) atomicAdd(&dd[yy * ws + xx], v);
+            }
+        }
+        __syncthreads();  // sD, sAcc reused by the next scale
+    }
+}
+
+// d_T[f][b] = K[:3,:]^T . sum_{tiles,scales} dP      (P = (K.T)[:3,:], learner_func.py:149)
+__global__ __launch_bounds__(NT) void chain_bwd_reduce_kernel(ChainParams p, BwdParams q) {
+    __shared__ float sRed[NT / 64][16];
+    __shared__ float sP[NDP];
+    const int b = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const int S = p.cfg.num_scales, ntiles = p.tiles_x * p.tiles_y;
+    const int col = tid & 15;
+    float v = 0.f;
+    if (col < NDP) {
+        for (int r = tid >> 4; r < ntiles * S; r += NT / 16) {
+            int t = r / S, s = r - t * S;
+            v += q.g.bwd_partials[((((size_t)b * ntiles + t) * S + s) * 2 + f) * NDP + col];
+        }
+    }
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if ((tid & 63) < 16) sRed[tid >> 6][col] = v;
+    __syncthreads();
+    if (tid < NDP) sP[tid] = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+    __syncthreads();
+    if (tid < 16) {
+        int k = tid >> 2, j = tid & 3;
+        const float* K = p.io.K + b * 16;
+        float acc = 0.f;
+        for (int i = 0; i < 3; ++i) acc += K[i * 4 + k] * sP[i * 4 + j];
+        q.g.d_T[f][b * 16 + tid] = acc;
+    }
+}
+
+int validate(const dvs_chain_cfg* c, const char* who) {
+    DVS_REQUIRE(c, "%s: null cfg", who);
+    DVS_REQUIRE(c->B > 0 && c->H >= 4 && c->W >= 4, "%s: bad size B=%d H=%d W=%d", who, c->B, c->H, c->W);
+    DVS_REQUIRE(c->num_scales >= 1 && c->num_scales <= DVS_MAX_SCALES, "%s: num_scales=%d", who, c->num_scales);
+    for (int s = 0; s < c->num_scales; ++s) {
+        DVS_REQUIRE(c->hs[s] > 0 && c->ws[s] > 0, "%s: scale %d is %dx%d", who, s, c->hs[s], c->ws[s]);
+        bool same = c->hs[s] == c->H && c->ws[s] == c->W;
+        DVS_REQUIRE(same || (c->hs[s] * 2 <= c->H && c->ws[s] * 2 <= c->W),
+                    "%s: scale %d (%dx%d) must be full resolution or at most half of %dx%d", who, s, c->hs[s],
+                    c->ws[s], c->H, c->W);
+    }
+    DVS_REQUIRE(c->min_depth > 0.f && c->max_depth > c->min_depth, "%s: depth range", who);
+    return DVS_OK;
+}
+
+ChainParams make_params(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io) {
+    ChainParams p;
+    p.cfg = *cfg;
+    p.io = *io;
+    p.tiles_x = (cfg->W + TW - 1) / TW;
+    p.tiles_y = (cfg->H + TH - 1) / TH;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_chain_workspace(const dvs_chain_cfg* cfg, size_t* partials_bytes, size_t* sel_bytes,
+                        size_t* stats_bytes, size_t* bwd_partials_bytes) {
+    int rc = validate(cfg, "dvs_chain_workspace");
+    if (rc) return rc;
+    size_t ntiles = (size_t)((cfg->W + TW - 1) / TW) * ((cfg->H + TH - 1) / TH);
+    if (partials_bytes) *partials_bytes = (size_t)cfg->B * ntiles * NPART * sizeof(float);
+    if (sel_bytes) *sel_bytes = (size_t)cfg->B * cfg->H * cfg->W;
+    if (stats_bytes) *stats_bytes = (size_t)cfg->B * cfg->num_scales * 4 * sizeof(float);
+    if (bwd_partials_bytes) *bwd_partials_bytes = (size_t)cfg->B * ntiles * cfg->num_scales * 2 * NDP * sizeof(float);
+    return DVS_OK;
+}
+
+int dvs_chain_fwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, void* stream) {
+    int rc = validate(cfg, "dvs_chain_fwd");
+    if (rc) return rc;
+    DVS_REQUIRE(io, "dvs_chain_fwd: null io");
+    DVS_REQUIRE(io->target && io->source[0] && io->source[1] && io->K && io->inv_K && io->T[0] && io->T[1],
+                "dvs_chain_fwd: null input");
+    DVS_REQUIRE(io->partials && io->sel && io->stats && io->losses, "dvs_chain_fwd: null workspace/output");
+    for (int s = 0; s < cfg->num_scales; ++s) DVS_REQUIRE(io->disp[s], "dvs_chain_fwd: null disp[%d]", s);
+    ChainParams p = make_params(cfg, io);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(chain_fwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(chain_fwd_reduce_kernel, dim3(cfg->B), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(chain_fwd_losses_kernel, dim3(1), dim3(64), 0, st, p);
+    return dvs::check_launch("dvs_chain_fwd");
+}
+
+int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dvs_chain_bwd_io* g,
+                  void* stream) {
+    int rc = validate(cfg, "dvs_chain_bwd");
+    if (rc) return rc;
+    DVS_REQUIRE(io && g, "dvs_chain_bwd: null io");
+    DVS_REQUIRE(io->target && io->source[0] && io->source[1] && io->K && io->inv_K && io->T[0] && io->T[1],
+                "dvs_chain_bwd: null input");
+    DVS_REQUIRE(io->sel && io->stats, "dvs_chain_bwd: null forward state");
+    DVS_REQUIRE(g->d_losses && g->d_T[0] && g->d_T[1] && g->bwd_partials, "dvs_chain_bwd: null gradient buffer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int s = 0; s < cfg->num_scales; ++s) {
+        DVS_REQUIRE(io->disp[s] && g->d_disp[s], "dvs_chain_bwd: null disp/d_disp[%d]", s);
+        if (!(cfg->hs[s] == cfg->H && cfg->ws[s] == cfg->W)) {
+            hipError_t e = hipMemsetAsync(g->d_disp[s], 0, (size_t)cfg->B * cfg->hs[s] * cfg->ws[s] * sizeof(float), st);
+            if (e != hipSuccess) return dvs::fail(DVS_ERR_LAUNCH, "dvs_chain_bwd: memset: %s", hipGetErrorString(e));
+        }
+    }
+    ChainParams p = make_params(cfg, io);
+    BwdParams q;
+    q.g = *g;
+    hipLaunchKernelGGL(chain_bwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p, q);
+    hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3(cfg->B, 2), dim3(NT), 0, st, p, q);
+    return dvs::check_launch("dvs_chain_bwd");
+}
+
+}  // extern "C"

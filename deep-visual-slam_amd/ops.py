@@ -1,0 +1,164 @@
+"""torch.autograd.Function wrappers over the C-ABI (include/dvslam.h).  PyTorch only provides device
+memory, the stream and the autograd graph here; all arithmetic is in libdvslam_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ChainBwdIO, ChainCfg, ChainFwdIO, check, ptr
+
+MAX_SCALES = _lib.MAX_SCALES
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.DvsError("fp32 tensors only (got %s)" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------- a4
+class _PoseToMat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        aa = _f32c(axisangle.reshape(-1, 3))
+        tr = _f32c(translation.reshape(-1, 3))
+        B = aa.shape[0]
+        M = torch.empty(B, 4, 4, device=aa.device, dtype=torch.float32)
+        check(_lib.lib().dvs_pose_to_mat_fwd(ptr(aa), ptr(tr), int(bool(invert)), ptr(M), B, _lib.stream()),
+              "dvs_pose_to_mat_fwd")
+        ctx.save_for_backward(aa, tr)
+        ctx.invert = int(bool(invert))
+        ctx.shapes = (axisangle.shape, translation.shape)
+        return M
+
+    @staticmethod
+    def backward(ctx, dM):
+        aa, tr = ctx.saved_tensors
+        dM = _f32c(dM)
+        d_aa, d_tr = torch.empty_like(aa), torch.empty_like(tr)
+        check(_lib.lib().dvs_pose_to_mat_bwd(ptr(aa), ptr(tr), ctx.invert, ptr(dM), ptr(d_aa), ptr(d_tr),
+                                             aa.shape[0], _lib.stream()), "dvs_pose_to_mat_bwd")
+        return d_aa.reshape(ctx.shapes[0]), d_tr.reshape(ctx.shapes[1]), None
+
+
+def pose_to_mat(axisangle, translation, invert=False):
+    """transformation_from_parameters (vo/learner_func.py:29-46) on the GPU."""
+    return _PoseToMat.apply(axisangle, translation, invert)
+
+
+# --------------------------------------------------------------------------------------- a5-a12
+def make_chain_cfg(B, H, W, disp_shapes, auto_mask=True, min_depth=0.1, max_depth=10.0, ssim_ratio=0.85,
+                   smoothness_ratio=1e-3):
+    cfg = ChainCfg()
+    cfg.B, cfg.H, cfg.W, cfg.num_scales = B, H, W, len(disp_shapes)
+    for s, (h, w) in enumerate(disp_shapes):
+        cfg.hs[s], cfg.ws[s] = h, w
+    cfg.auto_mask = int(bool(auto_mask))
+    cfg.min_depth, cfg.max_depth = min_depth, max_depth
+    cfg.ssim_ratio, cfg.smoothness_ratio = ssim_ratio, smoothness_ratio
+    return cfg
+
+
+def chain_workspace_bytes(cfg):
+    sizes = [C.c_size_t() for _ in range(4)]
+    check(_lib.lib().dvs_chain_workspace(C.byref(cfg), *[C.byref(s) for s in sizes]), "dvs_chain_workspace")
+    return [s.value for s in sizes]
+
+
+class _LossChain(torch.autograd.Function):
+    """losses[s] = loss/s of MonodepthTrainer._compute_losses (vo/learner_new.py:175-258) as one fused
+    forward launch; backward gives d/d disp_s and d/d cam_T_cam."""
+
+    @staticmethod
+    def forward(ctx, opts, target, src_l, src_r, K, inv_K, T_l, T_r, noise, *disps):
+        B, _, H, W = target.shape
+        dev = target.device
+        target, src_l, src_r = _f32c(target), _f32c(src_l), _f32c(src_r)
+        K, inv_K, T_l, T_r = _f32c(K), _f32c(inv_K), _f32c(T_l), _f32c(T_r)
+        disps = [_f32c(d) for d in disps]
+        S = len(disps)
+        cfg = make_chain_cfg(B, H, W, [tuple(d.shape[2:]) for d in disps], opts["auto_mask"], opts["min_depth"],
+                             opts["max_depth"], opts["ssim_ratio"], opts["smoothness_ratio"])
+        nb = chain_workspace_bytes(cfg)
+        partials = torch.empty(nb[0] // 4, device=dev, dtype=torch.float32)
+        sel = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+        stats = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+        losses = torch.empty(S, device=dev, dtype=torch.float32)
+        io = ChainFwdIO()
+        io.target = ptr(target)
+        io.source[0], io.source[1] = ptr(src_l), ptr(src_r)
+        for s in range(S):
+            io.disp[s] = ptr(disps[s])
+        io.K, io.inv_K = ptr(K), ptr(inv_K)
+        io.T[0], io.T[1] = ptr(T_l), ptr(T_r)
+        if noise is not None:
+            noise = _f32c(noise)
+            if tuple(noise.shape) != (S, B, 2, H, W):
+                raise _lib.DvsError("noise must be [S,B,2,H,W]")
+            io.noise = ptr(noise)
+        io.seed = int(opts.get("seed", 0))
+        io.partials, io.sel, io.stats, io.losses = ptr(partials), ptr(sel), ptr(stats), ptr(losses)
+        extra = []
+        if opts.get("materialize", False):
+            for s in range(S):
+                du = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+                dp = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32)
+                io.disp_up[s], io.depth[s] = ptr(du), ptr(dp)
+                extra += [du, dp]
+                for f in range(2):
+                    g = torch.empty(B, H, W, 2, device=dev, dtype=torch.float32)
+                    c = torch.empty(B, 3, H, W, device=dev, dtype=torch.float32)
+                    io.grid[s][f], io.color[s][f] = ptr(g), ptr(c)
+                    extra += [g, c]
+        check(_lib.lib().dvs_chain_fwd(C.byref(cfg), C.byref(io), _lib.stream()), "dvs_chain_fwd")
+        ctx.save_for_backward(target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps)
+        ctx.opts = dict(opts)
+        ctx.nbwd = nb[3]
+        ctx.mark_non_differentiable(sel, *extra)
+        return (losses, sel, *extra)
+
+    @staticmethod
+    def backward(ctx, d_losses, *_unused):
+        target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps = ctx.saved_tensors
+        B, _, H, W = target.shape
+        dev = target.device
+        S = len(disps)
+        opts = ctx.opts
+        cfg = make_chain_cfg(B, H, W, [tuple(d.shape[2:]) for d in disps], opts["auto_mask"], opts["min_depth"],
+                             opts["max_depth"], opts["ssim_ratio"], opts["smoothness_ratio"])
+        io = ChainFwdIO()
+        io.target = ptr(target)
+        io.source[0], io.source[1] = ptr(src_l), ptr(src_r)
+        for s in range(S):
+            io.disp[s] = ptr(disps[s])
+        io.K, io.inv_K = ptr(K), ptr(inv_K)
+        io.T[0], io.T[1] = ptr(T_l), ptr(T_r)
+        io.sel, io.stats = ptr(sel), ptr(stats)
+        g = ChainBwdIO()
+        d_losses = _f32c(d_losses)
+        g.d_losses = ptr(d_losses)
+        d_disps = [torch.empty_like(d) for d in disps]
+        for s in range(S):
+            g.d_disp[s] = ptr(d_disps[s])
+        d_T = [torch.empty(B, 4, 4, device=dev, dtype=torch.float32) for _ in range(2)]
+        g.d_T[0], g.d_T[1] = ptr(d_T[0]), ptr(d_T[1])
+        bwd_partials = torch.empty(ctx.nbwd // 4, device=dev, dtype=torch.float32)
+        g.bwd_partials = ptr(bwd_partials)
+        check(_lib.lib().dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), _lib.stream()), "dvs_chain_bwd")
+        return (None, None, None, None, None, None, d_T[0], d_T[1], None, *d_disps)
+
+
+def loss_chain(target, src_l, src_r, K, inv_K, T_l, T_r, disps, noise=None, seed=0, materialize=False,
+               auto_mask=True, min_depth=0.1, max_depth=10.0, ssim_ratio=0.85, smoothness_ratio=1e-3):
+    """Fused view-synthesis loss chain.  Returns (losses[S], sel[B,H,W] uint8, extras) where extras is a
+    per-scale list of dicts {disp_up, depth, grid:(l,r), color:(l,r)} when materialize=True, else []."""
+    opts = dict(auto_mask=auto_mask, min_depth=min_depth, max_depth=max_depth, ssim_ratio=ssim_ratio,
+                smoothness_ratio=smoothness_ratio, seed=seed, materialize=materialize)
+    out = _LossChain.apply(opts, target, src_l, src_r, K, inv_K, T_l, T_r, noise, *disps)
+    losses, sel, flat = out[0], out[1], out[2:]
+    extras = []
+    if materialize:
+        for s in range(len(disps)):
+            e = flat[s * 6:(s + 1) * 6]
+            extras.append({"disp_up": e[0], "depth": e[1], "grid": (e[2], e[4]), "color": (e[3], e[5])})
+    return losses, sel, extras

@@ -23,7 +23,8 @@ def close_frac(a, b, atol, rtol, frac=2e-3, l2=2e-3):
     and the relative L2 error of the whole tensor to stay small."""
     a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
     bad = np.abs(a - b) > atol + rtol * np.abs(b)
-    assert bad.mean() <= frac, "mismatch fraction %.2e" % bad.mean()
+    # one flipped full-resolution pixel touches 4 elements of a low-resolution gradient map
+    assert bad.sum() <= max(frac * bad.size, 8), "mismatch fraction %.2e (%d elements)" % (bad.mean(), bad.sum())
     num = np.linalg.norm(np.where(bad, 0, a - b).astype(np.float64))   # flipped pixels excluded
     den = np.linalg.norm(b.astype(np.float64)) + 1e-30
     assert num / den < l2, "rel L2 %.3e" % (num / den)
