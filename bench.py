@@ -1,0 +1,204 @@
+"""VO training-step throughput on MI355X (BASELINE.json metric: frames/s of 3-frame 640x480 snippets).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad -> DepthNet + 2x PoseNet forward -> fused 4-scale view-synthesis loss -> backward
+-> [bucketed RCCL gradient all-reduce] -> Adam, on one batch of synthetic triplets already resident in
+HBM.  Default workload: BASELINE.json configs[2]/[3] per GPU (batch 12, 4 scales,
+ResNet-18, fp32); `--config c2` selects configs[1] (batch 4, single scale).  Weak scaling: the
+per-GPU batch is fixed, `value` is the whole-job frames/s = 3 * B * N / t_step (max over ranks).
+Rank 0 prints one JSON line with `roofline` (dominant hand-written kernel, HIP-event timed inside
+the timed region) and, at N=1, `cpu_baseline` (the oracle's PyTorch-CPU restatement of the same step
+on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 480, 640
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3    # dense fp32 MFMA peak
+# compulsory loss-chain traffic per sample (fp32, ideally fused)
+CHAIN_FWD_BYTES = {4: 45.87e6, 1: 12.29e6}
+CONFIGS = {"c3": dict(batch=12, num_scales=4, name="configs[2]/[3]: full 4-scale photometric+smoothness loss, batch 12 per GPU, ResNet-18"),
+           "c2": dict(batch=4, num_scales=1, name="configs[1]: VO train step, batch 4, single-scale loss, ResNet-18")}
+
+
+def train_config(batch, num_scales):
+    return {"Train": dict(num_source=1, batch_size=batch, img_h=H, img_w=W, smoothness_ratio=0.001,
+                          auto_mask=True, ssim_ratio=0.85, min_depth=0.1, max_depth=10.0, use_compile=False)}
+
+
+def build_gpu(batch, num_scales, device, rank):
+    from deep_visual_slam_amd import dp, synth
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    torch.manual_seed(0)                      # same weights on every rank
+    depth_net = DepthNet(18, pretrained=False).to(device).train()
+    pose_net = PoseNet(18, pretrained=False, num_input_images=2).to(device).train()
+    flat = dp.FlatParams(dp.trainable_parameters(depth_net, pose_net))
+    sync = dp.GradSync(flat)
+    opt = dp.FusedAdam(flat, lr=1e-4)
+    trainer = MonodepthTrainer(depth_net, pose_net, train_config(batch, num_scales), device)
+    trainer.num_scales = num_scales
+    sample = synth.throughput_sample(batch, H, W, rank=rank, device=device)
+    return trainer, flat, sync, opt, sample
+
+
+def gpu_step(trainer, sync, opt, sample):
+    """vo/train.py:173-199 train_mono_step: forward, backward, all-reduce, Adam (+ fused zero_grad)."""
+    _, losses = trainer.process_batch(sample)
+    losses["loss"].backward()
+    sync.finish()
+    opt.step(grad_scale=sync.grad_scale, zero_grad=True)
+    return losses
+
+
+def cpu_baseline(batch, num_scales, steps=2, warmup=1):
+    """The reference's step on host cores: oracle networks + oracle loss chain + torch.optim.Adam."""
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    from oracle import loss_chain as OL, networks as ON
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    sd_d = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k)
+            for k, v in DepthNet(18, pretrained=False).state_dict().items()}
+    sd_p = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k)
+            for k, v in PoseNet(18, pretrained=False, num_input_images=2).state_dict().items()}
+    params = [v for v in list(sd_d.values()) + list(sd_p.values()) if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    sample = synth.throughput_sample(batch, H, W)
+    tgt, left, right = sample[("target_image", 0)], sample[("source_left", 0)], sample[("source_right", 0)]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        upd_d, upd_p = {}, {}
+        disp = ON.depthnet(tgt, sd_d, train=True, update=upd_d)
+        aa_l, t_l = ON.posenet(torch.cat([left, tgt], 1), sd_p, train=True, update=upd_p)
+        aa_r, t_r = ON.posenet(torch.cat([tgt, right], 1), sd_p, train=True, update=upd_p)
+        noise = [torch.randn(batch, 2, H, W) for _ in range(num_scales)]
+        _, losses = OL.loss_chain(sample, [disp[("disp", s)] for s in range(num_scales)], (aa_l, t_l, aa_r, t_r),
+                                  noise, num_scales=num_scales)
+        losses["loss"].backward()
+        opt.step()
+        return float(losses["loss"])
+
+    for _ in range(warmup):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 3.0 * batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d timed + %d warm-up train steps of the same workload at batch %d (%d-scale loss), "
+                      "oracle/networks.py + oracle/loss_chain.py on PyTorch-CPU fp32, %.2f s/step"
+                      % (steps, warmup, batch, num_scales, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    cfg = CONFIGS[args.config]
+    batch = args.batch or cfg["batch"]
+    num_scales = cfg["num_scales"]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from deep_visual_slam_amd import dp
+
+    trainer, flat, sync, opt, sample = build_gpu(batch, num_scales, device, rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gpu_step(trainer, sync, opt, sample)
+    barrier()
+    dp.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = gpu_step(trainer, sync, opt, sample)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = dp.profile_read()
+    dp.profile_enable(False)
+    loss_val = float(losses["loss"])
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    value = 3.0 * batch * world * args.steps / dt
+
+    if rank == 0:
+        # roofline of the dominant hand-written kernel inside the timed region
+        per_kernel = {k: (ms / n, n) for k, (ms, n) in prof.items()}
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        roof = None
+        if dom in ("chain_fwd_kernel", "chain_bwd_kernel"):
+            nbytes = CHAIN_FWD_BYTES[num_scales] * batch      # fwd and bwd move the same compulsory bytes
+            avg_s = per_kernel[dom][0] * 1e-3
+            ach = nbytes / avg_s / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": per_kernel[dom][0],
+                    "algorithmic_bytes_per_launch": nbytes}
+        out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": cfg["name"], "per_gpu_batch": batch, "global_batch": batch * world,
+                          "num_scales": num_scales, "image": "%dx%d" % (W, H),
+                          "parallelism": "dp%d" % world, "conv_backend": os.environ.get("DVS_CONV_BACKEND", "hip")},
+               "loss": loss_val,
+               "kernels_ms": {k: round(v[0], 4) for k, v in per_kernel.items()},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, num_scales)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

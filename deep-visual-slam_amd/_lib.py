@@ -45,11 +45,27 @@ _SIGNATURES = {
     "dvs_last_error": (C.c_char_p, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),
+    "dvs_profile_enable": (C.c_int, [C.c_int]),
+    "dvs_profile_slots": (C.c_int, []),
+    "dvs_profile_slot_name": (C.c_char_p, [C.c_int]),
+    "dvs_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "dvs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int, C.c_float, C.c_int, _vp]),
     "dvs_pose_to_mat_fwd": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_pose_to_mat_bwd": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "dvs_chain_workspace": (C.c_int, [C.POINTER(ChainCfg)] + [C.POINTER(C.c_size_t)] * 4),
     "dvs_chain_fwd": (C.c_int, [C.POINTER(ChainCfg), C.POINTER(ChainFwdIO), _vp]),
     "dvs_chain_bwd": (C.c_int, [C.POINTER(ChainCfg), C.POINTER(ChainFwdIO), C.POINTER(ChainBwdIO), _vp]),
+    "dvs_backproject_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_backproject_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_project_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_project_bwd_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "dvs_project_bwd": (C.c_int, [_vp] * 7 + [C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_ssim_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_ssim_bwd": (C.c_int, [_vp] * 5 + [C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_smooth_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "dvs_smooth_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
+    "dvs_smooth_bwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
 }
 
 _lib = None

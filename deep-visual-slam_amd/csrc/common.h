@@ -24,6 +24,26 @@ inline int check_launch(const char* what) {
         if (!(cond)) return dvs::fail(DVS_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// ---- per-kernel timing with HIP events on the launch stream (include/dvslam.h: dvs_profile_*)
+enum ProfSlot { SLOT_CHAIN_FWD = 0, SLOT_CHAIN_BWD, SLOT_ADAM, SLOT_CONV_FWD, SLOT_CONV_DGRAD, SLOT_CONV_WGRAD,
+                SLOT_BN_FWD, SLOT_BN_BWD, SLOT_COUNT };
+bool prof_enabled();
+void prof_begin(int slot, hipStream_t st, hipEvent_t* start);
+void prof_end(int slot, hipStream_t st, hipEvent_t start);
+
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    hipEvent_t start = nullptr;
+    bool on;
+    ProfScope(int s, hipStream_t stream) : slot(s), st(stream), on(prof_enabled()) {
+        if (on) prof_begin(slot, st, &start);
+    }
+    ~ProfScope() {
+        if (on) prof_end(slot, st, start);
+    }
+};
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 // 64-lane butterfly sum; every lane ends with the total.

@@ -1,7 +1,10 @@
 // Library-level entry points of libdvslam_hip.so (include/dvslam.h: "library").
 #include "common.h"
 
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace dvs {
 
@@ -18,9 +21,84 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ------------------------------------------------------------------ HIP-event kernel timing
+namespace {
+struct Pair {
+    hipEvent_t a, b;
+};
+std::mutex g_mu;
+std::atomic<bool> g_on{false};
+std::vector<Pair> g_pairs[SLOT_COUNT];
+double g_ms[SLOT_COUNT];
+long g_n[SLOT_COUNT];
+const char* kSlotNames[SLOT_COUNT] = {"chain_fwd_kernel", "chain_bwd_kernel", "adam_kernel", "conv_fwd_kernel",
+                                      "conv_dgrad_kernel", "conv_wgrad_kernel", "bn_fwd_kernel", "bn_bwd_kernel"};
+
+void drain_locked(int slot) {
+    for (Pair& p : g_pairs[slot]) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_ms[slot] += ms;
+            g_n[slot] += 1;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_pairs[slot].clear();
+}
+}  // namespace
+
+bool prof_enabled() { return g_on.load(std::memory_order_relaxed); }
+
+void prof_begin(int, hipStream_t st, hipEvent_t* start) {
+    if (hipEventCreate(start) != hipSuccess) {
+        *start = nullptr;
+        return;
+    }
+    (void)hipEventRecord(*start, st);
+}
+
+void prof_end(int slot, hipStream_t st, hipEvent_t start) {
+    if (!start) return;
+    hipEvent_t stop;
+    if (hipEventCreate(&stop) != hipSuccess) {
+        (void)hipEventDestroy(start);
+        return;
+    }
+    (void)hipEventRecord(stop, st);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pairs[slot].push_back({start, stop});
+}
+
 }  // namespace dvs
 
 extern "C" {
+
+int dvs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(dvs::g_mu);
+    for (int s = 0; s < dvs::SLOT_COUNT; ++s) {
+        dvs::drain_locked(s);
+        dvs::g_ms[s] = 0.0;
+        dvs::g_n[s] = 0;
+    }
+    dvs::g_on.store(on != 0);
+    return DVS_OK;
+}
+
+int dvs_profile_slots(void) { return dvs::SLOT_COUNT; }
+
+const char* dvs_profile_slot_name(int slot) {
+    return (slot >= 0 && slot < dvs::SLOT_COUNT) ? dvs::kSlotNames[slot] : "";
+}
+
+int dvs_profile_read(int slot, double* total_ms, long* launches) {
+    DVS_REQUIRE(slot >= 0 && slot < dvs::SLOT_COUNT && total_ms && launches, "dvs_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(dvs::g_mu);
+    dvs::drain_locked(slot);
+    *total_ms = dvs::g_ms[slot];
+    *launches = dvs::g_n[slot];
+    return DVS_OK;
+}
 
 const char* dvs_last_error(void) { return dvs::err_buf(); }
 

@@ -766,7 +766,10 @@ int dvs_chain_fwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, void* st
     for (int s = 0; s < cfg->num_scales; ++s) DVS_REQUIRE(io->disp[s], "dvs_chain_fwd: null disp[%d]", s);
     ChainParams p = make_params(cfg, io);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(chain_fwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p);
+    {
+        dvs::ProfScope prof(dvs::SLOT_CHAIN_FWD, st);
+        hipLaunchKernelGGL(chain_fwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p);
+    }
     hipLaunchKernelGGL(chain_fwd_reduce_kernel, dim3(cfg->B), dim3(NT), 0, st, p);
     hipLaunchKernelGGL(chain_fwd_losses_kernel, dim3(1), dim3(64), 0, st, p);
     return dvs::check_launch("dvs_chain_fwd");
@@ -792,7 +795,10 @@ int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dv
     ChainParams p = make_params(cfg, io);
     BwdParams q;
     q.g = *g;
-    hipLaunchKernelGGL(chain_bwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p, q);
+    {
+        dvs::ProfScope prof(dvs::SLOT_CHAIN_BWD, st);
+        hipLaunchKernelGGL(chain_bwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p, q);
+    }
     hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3(cfg->B, 2), dim3(NT), 0, st, p, q);
     return dvs::check_launch("dvs_chain_bwd");
 }

@@ -1,0 +1,162 @@
+"""Data-parallel training plumbing: one process per GPU, flat fp32 arenas, bucketed gradient
+all-reduce over RCCL (torch.distributed backend "nccl" on ROCm), fused Adam on the arena.
+
+The reference has no distributed code at all: `vo/train.py` builds one
+`torch.optim.Adam` over both networks on one device.  This module keeps that optimiser's arithmetic
+(dvs_adam_step) and adds the only exchange step the path has under data parallelism over frame
+triplets: one sum all-reduce of the 26.8 M gradients per step, scaled by 1/world_size inside the
+Adam pass.  BatchNorm statistics stay per rank (the reference has no SyncBN).
+
+Layout: every tensor that can receive a gradient lives back to back in `FlatParams.params`
+(16-byte aligned slots) with its gradient at the same offset of `FlatParams.grads`; nn.Parameter
+`.data` / `.grad` are views, so autograd accumulates straight into the arena.  Slots are ordered by
+expected backward completion (PoseNet decoder -> encoder, then DepthNet decoder -> encoder, i.e.
+reverse construction order), so the buckets fill front to back and each bucket's all-reduce is
+issued while the remaining backward still runs.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def trainable_parameters(*modules):
+    """Named parameters that receive gradients on this path: everything except torchvision's unused
+    `fc` head, which the reference keeps in its state_dict but never runs."""
+    out = []
+    for mi, m in enumerate(modules):
+        for n, p in m.named_parameters():
+            if p.requires_grad and ".fc." not in n:
+                out.append(("%d.%s" % (mi, n), p))
+    return out
+
+
+class FlatParams:
+    def __init__(self, named_params, align=4):
+        named_params = list(named_params)[::-1]          # reverse construction order = backward order
+        self.names = [n for n, _ in named_params]
+        self.tensors = [p for _, p in named_params]
+        dev = self.tensors[0].device
+        self.offsets = []
+        off = 0
+        for p in self.tensors:
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align
+        self.numel = off
+        self.params = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(self.tensors, self.offsets):
+            n = p.numel()
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def reattach(self):
+        """Re-point .grad at the arena (e.g. after a caller ran zero_grad(set_to_none=True))."""
+        for p, o in zip(self.tensors, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
+                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+
+
+class GradSync:
+    """Bucketed sum all-reduce of FlatParams.grads, overlapped with backward."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = []          # (start, end) element ranges
+        self.bucket_of = []
+        cap = bucket_bytes // 4
+        start = 0
+        for i, (p, o) in enumerate(zip(flat.tensors, flat.offsets)):
+            end = flat.offsets[i + 1] if i + 1 < len(flat.offsets) else flat.numel
+            self.bucket_of.append(len(self.buckets))
+            if end - start >= cap or i + 1 == len(flat.tensors):
+                self.buckets.append((start, end))
+                start = end
+        self.sizes = [0] * len(self.buckets)
+        for b in self.bucket_of:
+            self.sizes[b] += 1
+        self._ready = [0] * len(self.buckets)
+        self._work = []
+        if self.world > 1:
+            for i, p in enumerate(flat.tensors):
+                p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
+
+    def _make_hook(self, b):
+        def hook(_param):
+            self._ready[b] += 1
+            if self._ready[b] == self.sizes[b]:
+                s, e = self.buckets[b]
+                self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                  async_op=True))
+        return hook
+
+    def finish(self):
+        """Wait for the step's all-reduces (any bucket whose hooks did not all fire is reduced now)."""
+        if self.world > 1:
+            for b, (s, e) in enumerate(self.buckets):
+                if self._ready[b] != self.sizes[b]:
+                    self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                      async_op=True))
+            for w in self._work:
+                w.wait()
+        self._work = []
+        self._ready = [0] * len(self.buckets)
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr, betas, eps) semantics on the flat arena (dvs_adam_step)."""
+
+    def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.flat = flat
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.exp_avg = torch.zeros_like(flat.params)
+        self.exp_avg_sq = torch.zeros_like(flat.params)
+        self.step_count = 0
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps}]   # scheduler-compatible view
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        self.step_count += 1
+        lr = self.param_groups[0]["lr"]
+        f = self.flat
+        check(_lib.lib().dvs_adam_step(ptr(f.params), ptr(f.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                       f.numel, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                                       grad_scale, int(zero_grad), _lib.stream()), "dvs_adam_step")
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = sd["param_groups"]
+
+
+def profile_enable(on=True):
+    check(_lib.lib().dvs_profile_enable(int(on)), "dvs_profile_enable")
+
+
+def profile_read():
+    """{kernel_name: (total_ms, launches)} for every slot that recorded launches."""
+    l = _lib.lib()
+    out = {}
+    for s in range(l.dvs_profile_slots()):
+        ms, n = C.c_double(), C.c_long()
+        check(l.dvs_profile_read(s, C.byref(ms), C.byref(n)), "dvs_profile_read")
+        if n.value:
+            out[l.dvs_profile_slot_name(s).decode()] = (ms.value, n.value)
+    return out

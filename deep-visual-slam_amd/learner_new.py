@@ -1,0 +1,138 @@
+"""MonodepthTrainer -- drop-in for the reference's vo/learner_new.py:15-258.
+
+Same constructor, attributes and `process_batch(sample) -> (outputs, losses)` contract; the 4x2
+scale/frame loop of `_generate_images_pred` and the loss loop of `_compute_losses` (about 600 eager
+kernels per step in the reference) are one fused forward launch and one fused backward launch of
+libdvslam_hip.so (ops.loss_chain).  The per-scale view-synthesis tensors of the reference's `outputs`
+dict (("disp_up",s), ("depth",s), ("sample",f,s), ("color",f,s), "identity_selection/s") are only
+consumed by the plotting code every `train_plot_interval` steps (vo/train.py:268), so they are
+materialised lazily on first access (or eagerly with config["Train"]["materialize_outputs"]).
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import SSIM, BackprojectDepth, Project3D
+
+
+class LazyOutputs(dict):
+    """`outputs` dict whose view-synthesis tensors are produced on first access."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._thunk = None
+
+    def __missing__(self, key):
+        if self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            thunk(self)
+            if dict.__contains__(self, key):
+                return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def materialize(self):
+        if self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            thunk(self)
+        return self
+
+
+class MonodepthTrainer:
+    def __init__(self, depth_net: nn.Module, pose_net: nn.Module, config: dict, device: torch.device):
+        self.depth_net = depth_net
+        self.pose_net = pose_net
+        self.config = config
+        self.device = device
+
+        tr = config["Train"]
+        self.num_scales = 4
+        self.num_source = tr["num_source"]
+        self.batch_size = tr["batch_size"]
+        self.image_shape = (tr["img_h"], tr["img_w"])
+        self.smoothness_ratio = tr["smoothness_ratio"]
+        self.auto_mask = tr["auto_mask"]
+        self.ssim_ratio = tr["ssim_ratio"]
+        self.min_depth = tr["min_depth"]
+        self.max_depth = tr["max_depth"]
+        self.use_compile = tr["use_compile"]   # accepted for compatibility; there is no tracing compiler here
+        self.materialize_outputs = bool(tr.get("materialize_outputs", False))
+        self.noise_seed = int(tr.get("noise_seed", 0))
+        self._step = 0
+        self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]
+
+        # standalone operators kept as public attributes like the reference (learner_new.py:44-57)
+        self.ssim = SSIM().to(self.device)
+        self.backproject_depth = BackprojectDepth(self.batch_size, self.image_shape[0], self.image_shape[1]).to(self.device)
+        self.project_3d = Project3D(self.batch_size, self.image_shape[0], self.image_shape[1]).to(self.device)
+
+    def _compute_reprojection_loss(self, pred: torch.Tensor, target: torch.Tensor):
+        """learner_new.py:60-74 (standalone form; the training step uses the fused chain)."""
+        l1_loss = torch.abs(target - pred).mean(1, True)
+        ssim_loss = self.ssim(pred, target).mean(1, True)
+        return self.ssim_ratio * ssim_loss + (1 - self.ssim_ratio) * l1_loss
+
+    def process_batch(self, sample: Dict[str, torch.Tensor]):
+        for key in sample:
+            if isinstance(sample[key], torch.Tensor):
+                sample[key] = sample[key].to(self.device, non_blocking=True)
+        outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
+        outputs.update(self._predict_poses(sample))
+        losses = self._fused_losses(sample, outputs)
+        return outputs, losses
+
+    def _predict_poses(self, sample):
+        """learner_new.py:107-129."""
+        outputs = {}
+        left, tgt, right = sample[("source_left", 0)], sample[("target_image", 0)], sample[("source_right", 0)]
+        axisangle_left, translation_left = self.pose_net(torch.cat([left, tgt], dim=1))
+        axisangle_right, translation_right = self.pose_net(torch.cat([tgt, right], dim=1))
+        outputs[("axisangle", 0, -1)] = axisangle_left
+        outputs[("translation", 0, -1)] = translation_left
+        outputs[("axisangle", 0, 1)] = axisangle_right
+        outputs[("translation", 0, 1)] = translation_right
+        outputs[("cam_T_cam", 0, -1)] = ops.pose_to_mat(axisangle_left[:, 0], translation_left[:, 0], invert=True)
+        outputs[("cam_T_cam", 0, 1)] = ops.pose_to_mat(axisangle_right[:, 0], translation_right[:, 0], invert=False)
+        return outputs
+
+    def _chain_args(self, sample, outputs):
+        disps = [outputs[("disp", s)] for s in range(self.num_scales)]
+        return (sample[("target_image", 0)], sample[("source_left", 0)], sample[("source_right", 0)],
+                sample[("K", 0)], sample[("inv_K", 0)], outputs[("cam_T_cam", 0, -1)],
+                outputs[("cam_T_cam", 0, 1)], disps)
+
+    def _chain_kwargs(self, seed):
+        return dict(noise=self._noise, seed=seed, auto_mask=self.auto_mask, min_depth=self.min_depth,
+                    max_depth=self.max_depth, ssim_ratio=self.ssim_ratio, smoothness_ratio=self.smoothness_ratio)
+
+    def _fused_losses(self, sample, outputs):
+        """_generate_images_pred + _compute_losses (learner_new.py:132-258) as one fused launch."""
+        seed = self.noise_seed + self._step
+        self._step += 1
+        args = self._chain_args(sample, outputs)
+        loss_vec, sel, extras = ops.loss_chain(*args, materialize=self.materialize_outputs, **self._chain_kwargs(seed))
+        losses = {"loss/{}".format(s): loss_vec[s] for s in range(self.num_scales)}
+        losses["loss"] = loss_vec.sum() / self.num_scales
+        srcs = {-1: sample[("source_left", 0)], 1: sample[("source_right", 0)]}
+
+        def fill(out, sel=sel, extras=extras):
+            if not extras:
+                with torch.no_grad():
+                    dargs = [a.detach() if isinstance(a, torch.Tensor) else [d.detach() for d in a] for a in args]
+                    _, sel, extras = ops.loss_chain(*dargs, materialize=True, **self._chain_kwargs(seed))
+            for s in range(self.num_scales):
+                e = extras[s]
+                out[("disp_up", s)], out[("depth", s)] = e["disp_up"], e["depth"]
+                for i, f in enumerate((-1, 1)):
+                    out[("sample", f, s)] = e["grid"][i]
+                    out[("color", f, s)] = e["color"][i]
+                    out[("color_identity", f, s)] = srcs[f]
+                if self.auto_mask:
+                    out["identity_selection/{}".format(s)] = (((sel >> (2 * s)) & 3) > 1).float().unsqueeze(1)
+
+        if self.materialize_outputs:
+            fill(outputs)
+        else:
+            outputs._thunk = fill
+        return losses

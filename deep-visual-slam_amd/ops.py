@@ -162,3 +162,113 @@ def loss_chain(target, src_l, src_r, K, inv_K, T_l, T_r, disps, noise=None, seed
             e = flat[s * 6:(s + 1) * 6]
             extras.append({"disp_up": e[0], "depth": e[1], "grid": (e[2], e[4]), "color": (e[3], e[5])})
     return losses, sel, extras
+
+
+# ------------------------------------------------------------------- standalone operators (a6-a11)
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        depth, inv_K = _f32c(depth), _f32c(inv_K)
+        B, _, H, W = depth.shape
+        cam = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
+        check(_lib.lib().dvs_backproject_fwd(ptr(depth), ptr(inv_K), ptr(cam), B, H, W, _lib.stream()),
+              "dvs_backproject_fwd")
+        ctx.save_for_backward(inv_K)
+        ctx.shape = depth.shape
+        return cam
+
+    @staticmethod
+    def backward(ctx, d_cam):
+        (inv_K,) = ctx.saved_tensors
+        B, _, H, W = ctx.shape
+        d_depth = torch.empty(ctx.shape, device=d_cam.device, dtype=torch.float32)
+        check(_lib.lib().dvs_backproject_bwd(ptr(_f32c(d_cam)), ptr(inv_K), ptr(d_depth), B, H, W, _lib.stream()),
+              "dvs_backproject_bwd")
+        return d_depth, None
+
+
+def backproject(depth, inv_K):
+    return _Backproject.apply(depth, inv_K)
+
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps):
+        points, K, T = _f32c(points), _f32c(K), _f32c(T)
+        B = points.shape[0]
+        grid = torch.empty(B, H, W, 2, device=points.device, dtype=torch.float32)
+        check(_lib.lib().dvs_project_fwd(ptr(points), ptr(K), ptr(T), ptr(grid), B, H, W, eps, _lib.stream()),
+              "dvs_project_fwd")
+        ctx.save_for_backward(points, K, T)
+        ctx.dims = (B, H, W, eps)
+        return grid
+
+    @staticmethod
+    def backward(ctx, d_grid):
+        points, K, T = ctx.saved_tensors
+        B, H, W, eps = ctx.dims
+        l = _lib.lib()
+        d_points = torch.empty_like(points)
+        d_T = torch.empty(B, 4, 4, device=points.device, dtype=torch.float32)
+        ws = torch.empty(l.dvs_project_bwd_workspace(B, H, W) // 4, device=points.device, dtype=torch.float32)
+        check(l.dvs_project_bwd(ptr(points), ptr(K), ptr(T), ptr(_f32c(d_grid)), ptr(d_points), ptr(d_T), ptr(ws),
+                                B, H, W, eps, _lib.stream()), "dvs_project_bwd")
+        return d_points, None, d_T, None, None, None
+
+
+def project(points, K, T, H, W, eps=1e-7):
+    return _Project.apply(points, K, T, H, W, eps)
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _f32c(x), _f32c(y)
+        B, Cc, H, W = x.shape
+        out = torch.empty_like(x)
+        check(_lib.lib().dvs_ssim_fwd(ptr(x), ptr(y), ptr(out), B * Cc, H, W, _lib.stream()), "dvs_ssim_fwd")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, y = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().dvs_ssim_bwd(ptr(x), ptr(y), ptr(_f32c(d_out)), ptr(dx), ptr(dy), B * Cc, H, W,
+                                      _lib.stream()), "dvs_ssim_bwd")
+        return dx, dy
+
+
+def ssim(x, y):
+    return _SSIM.apply(x, y)
+
+
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        disp, img = _f32c(disp), _f32c(img)
+        B, Cd, H, W = disp.shape
+        if Cd != 1:
+            raise _lib.DvsError("get_smooth_loss: disparity must have one channel")
+        l = _lib.lib()
+        out = torch.empty(1, device=disp.device, dtype=torch.float32)
+        ws = torch.empty(l.dvs_smooth_workspace(B, H, W) // 4, device=disp.device, dtype=torch.float32)
+        check(l.dvs_smooth_fwd(ptr(disp), ptr(img), ptr(out), ptr(ws), B, img.shape[1], H, W, _lib.stream()),
+              "dvs_smooth_fwd")
+        ctx.save_for_backward(disp, img)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, d_out):
+        disp, img = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        d_disp = torch.empty_like(disp)
+        check(_lib.lib().dvs_smooth_bwd(ptr(disp), ptr(img), ptr(_f32c(d_out.reshape(1))), ptr(d_disp), B,
+                                        img.shape[1], H, W, _lib.stream()), "dvs_smooth_bwd")
+        return d_disp, None
+
+
+def smooth_loss(disp, img):
+    return _Smooth.apply(disp, img)

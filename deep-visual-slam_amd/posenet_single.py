@@ -1,0 +1,51 @@
+"""PoseNet -- drop-in for the reference's model/posenet_single.py:149-202.
+
+`FlowPoseNet` exists as a name only because vo/train.py:18 imports it; the trainer never constructs
+it (it needs the RAFT checkpoint that is absent from the reference tree)."""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nn_ops
+from .resnet_encoder import ResnetEncoder
+
+
+class PoseNet(nn.Module):
+    """Pose estimation network with ResNet encoder and pose decoder"""
+
+    def __init__(self, num_layers=18, pretrained=True, num_input_images=2, stride=1):
+        super().__init__()
+        self.num_input_images = num_input_images
+        self.stride = stride
+        self.encoder = ResnetEncoder(num_layers=num_layers, pretrained=pretrained,
+                                     num_input_images=num_input_images)
+        self.num_ch_enc = self.encoder.num_ch_enc
+        self.convs = OrderedDict()
+        self.convs[("squeeze")] = nn.Conv2d(self.num_ch_enc[-1], 256, 1)
+        self.convs[("pose", 0)] = nn.Conv2d(256, 256, 3, stride, 1)
+        self.convs[("pose", 1)] = nn.Conv2d(256, 256, 3, stride, 1)
+        self.convs[("pose", 2)] = nn.Conv2d(256, 6, 1)
+        self.relu = nn.ReLU()
+        self.net = nn.ModuleList(list(self.convs.values()))
+
+    def forward(self, input_images):
+        feature = self.encoder(input_images)
+        sq = self.convs["squeeze"]
+        out = F.relu(nn_ops.conv2d(feature[-1], sq.weight, sq.bias, 1, 0))
+        for i in range(3):
+            c = self.convs[("pose", i)]
+            out = nn_ops.conv2d(out, c.weight, c.bias, c.stride[0], c.padding[0])
+            if i != 2:
+                out = F.relu(out)
+        out = out.mean(3).mean(2)
+        out = 0.01 * out.view(-1, 1, 1, 6)
+        return out[..., :3], out[..., 3:]
+
+
+class FlowPoseNet(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("FlowPoseNet (RAFT-based alternate, model/posenet_single.py:91-147) is "
+                                  "off the hot path: vo/train.py imports the name but constructs PoseNet")

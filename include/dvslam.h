@@ -46,6 +46,26 @@ int dvs_abi_version(void);
 /* Name of the code-object architecture the kernels were compiled for ("gfx950"). */
 const char* dvs_arch(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream around each main kernel (used by
+ * bench.py for the roofline line; off by default).  dvs_profile_enable(1) clears the counters;
+ * dvs_profile_read synchronises the recorded events of one slot and returns the accumulated
+ * kernel time and launch count.  Slot names are the kernel names seen by rocprofv3. */
+int dvs_profile_enable(int on);
+int dvs_profile_slots(void);
+const char* dvs_profile_slot_name(int slot);
+int dvs_profile_read(int slot, double* total_ms, long* launches);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13  Adam over a flat fp32 arena: one pass replaces torch.optim.Adam(params, lr) + zero_grad of
+ *      the reference trainer (vo/train.py:114-117,175,192).  torch.optim.Adam arithmetic (no weight
+ *      decay, no amsgrad): m,v updates, bias corrections, p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2)+eps).
+ *      grad is multiplied by grad_scale first (1/world_size after a sum all-reduce); zero_grad != 0
+ *      clears grad in the same pass.  All four buffers hold n floats and are 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int dvs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                  float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad,
+                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion
  *     replaces transformation_from_parameters / rot_from_axisangle / get_translation_matrix
@@ -93,7 +113,7 @@ typedef struct {
     /* workspace (sizes from dvs_chain_workspace) */
     float* partials;                 /* per-block partial sums */
     uint8_t* sel;                    /* [B,H,W] argmin of the 4-way min, 2 bits per scale */
-    float* stats;                    /* [B,S,4] per-image {mean_disp, Gx, Gy, unused} */
+    float* stats;                    /* [B,S,4] per-image sums {min-loss, disp_up, Gx, Gy} */
     /* outputs */
     float* losses;                   /* [S] losses["loss/s"] */
     /* optional materialised tensors of the reference's `outputs` dict (NULL = skip) */
@@ -105,7 +125,7 @@ typedef struct {
 
 typedef struct {
     const float* d_losses;           /* [S] upstream gradient of losses["loss/s"] */
-    float* d_disp[DVS_MAX_SCALES];   /* [B,1,hs,ws]; must be zero-filled by the caller for s>0 */
+    float* d_disp[DVS_MAX_SCALES];   /* [B,1,hs,ws]; overwritten (zero-filled inside where needed) */
     float* d_T[2];                   /* [B,4,4] gradient wrt cam_T_cam(-1/+1) */
     float* bwd_partials;             /* workspace */
 } dvs_chain_bwd_io;
@@ -117,6 +137,41 @@ int dvs_chain_fwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, void* st
 /* Needs the same inputs/workspace as the forward call it differentiates (sel, stats filled). */
 int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dvs_chain_bwd_io* g,
                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Standalone (un-fused) operators for callers that use model/layers.py piecewise
+ * ------------------------------------------------------------------------------------------- */
+/* BackprojectDepth.forward (vo/learner_func.py:130-135): depth [B,1,H,W], inv_K [B,4,4] ->
+ * cam_points [B,4,H*W] (row 3 = 1).  bwd: d_depth = sum_{r<3} d_cam[r] * (inv_K[:3,:3].[x,y,1])[r]. */
+int dvs_backproject_fwd(const float* depth, const float* inv_K, float* cam_points, int B, int H, int W,
+                        void* stream);
+int dvs_backproject_bwd(const float* d_cam_points, const float* inv_K, float* d_depth, int B, int H,
+                        int W, void* stream);
+
+/* Project3D.forward (vo/learner_func.py:148-159): points [B,4,H*W], K,T [B,4,4] -> grid [B,H,W,2]
+ * normalised to [-1,1].  bwd: d_points [B,4,H*W], d_T [B,4,4]; workspace bytes from
+ * dvs_project_bwd_workspace. */
+int dvs_project_fwd(const float* points, const float* K, const float* T, float* grid, int B, int H,
+                    int W, float eps, void* stream);
+size_t dvs_project_bwd_workspace(int B, int H, int W);
+int dvs_project_bwd(const float* points, const float* K, const float* T, const float* d_grid,
+                    float* d_points, float* d_T, float* workspace, int B, int H, int W, float eps,
+                    void* stream);
+
+/* SSIM.forward (vo/learner_func.py:193-207) on `planes` = B*C independent [H,W] planes:
+ * clamp((1 - SSIM)/2, 0, 1) with ReflectionPad2d(1) + AvgPool2d(3,1).  bwd: d_x and/or d_y (either
+ * may be NULL). */
+int dvs_ssim_fwd(const float* x, const float* y, float* out, int planes, int H, int W, void* stream);
+int dvs_ssim_bwd(const float* x, const float* y, const float* d_out, float* d_x, float* d_y,
+                 int planes, int H, int W, void* stream);
+
+/* get_smooth_loss (vo/learner_func.py:161-174): disp [B,1,H,W], img [B,C,H,W] -> out[1] (device
+ * scalar).  bwd: d_disp = d_out[0] * d out / d disp (the image is data). */
+size_t dvs_smooth_workspace(int B, int H, int W);
+int dvs_smooth_fwd(const float* disp, const float* img, float* out, float* workspace, int B, int C,
+                   int H, int W, void* stream);
+int dvs_smooth_bwd(const float* disp, const float* img, const float* d_out, float* d_disp, int B,
+                   int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

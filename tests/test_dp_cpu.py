@@ -1,0 +1,104 @@
+"""Data-parallel path on CPU: flat arena + bucketed all-reduce over gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1),
+                               torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from deep_visual_slam_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _model()
+    flat = dp.FlatParams(dp.trainable_parameters(m))
+    sync = dp.GradSync(flat, bucket_bytes=256)          # tiny buckets -> several all-reduces per step
+    assert len(sync.buckets) > 1
+    torch.manual_seed(100)
+    x = torch.randn(4, 3, 8, 8)
+    res = []
+    for step in range(2):                                 # two steps: bucket bookkeeping must reset
+        xs = x[rank * 2:(rank + 1) * 2] + step
+        loss = m(xs).pow(2).mean()
+        loss.backward()
+        sync.finish()
+        res.append((flat.grads * sync.grad_scale).clone())
+        flat.zero_grad()
+    q.put((rank, [r.numpy() for r in res], flat.names, flat.offsets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    # single-process reference on the full batch (mean over ranks of rank-mean losses == full-batch mean)
+    from deep_visual_slam_amd import dp
+    m = _model()
+    flat = dp.FlatParams(dp.trainable_parameters(m))
+    torch.manual_seed(100)
+    x = torch.randn(4, 3, 8, 8)
+    for step in range(2):
+        m(x + step).pow(2).mean().backward()
+        ref = flat.grads.clone().numpy()
+        flat.zero_grad()
+        for r in range(world):
+            assert abs(got[r][1][step] - ref).max() < 1e-6
+    assert (got[0][1][0] == got[1][1][0]).all()           # ranks hold identical reduced gradients
+
+
+def test_flat_params_are_views_in_backward_order():
+    from deep_visual_slam_amd import dp
+    m = _model()
+    flat = dp.FlatParams(dp.trainable_parameters(m))
+    assert flat.names[0].endswith("4.bias") and flat.names[-1].endswith("0.weight")
+    assert all(o % 4 == 0 for o in flat.offsets)
+    for p, o in zip(flat.tensors, flat.offsets):
+        assert p.data_ptr() == flat.params.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == flat.grads.data_ptr() + 4 * o
+    m(torch.randn(1, 3, 4, 4)).sum().backward()
+    assert float(flat.grads.abs().sum()) > 0
+    for p in m.parameters():
+        p.grad = None
+    flat.reattach()
+    assert all(p.grad is not None for p in m.parameters())
+
+
+def test_fc_head_is_excluded():
+    from deep_visual_slam_amd import dp
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    torch.manual_seed(0)
+    named = dp.trainable_parameters(DepthNet(18, False), PoseNet(18, False, 2))
+    assert sum(p.numel() for _, p in named) == 26828186
+    assert not any(".fc." in n for n, _ in named)
