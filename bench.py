@@ -71,7 +71,8 @@ def cpu_baseline(batch, num_scales, steps=2, warmup=1):
     from deep_visual_slam_amd.depthnet import DepthNet
     from deep_visual_slam_amd.posenet_single import PoseNet
     from oracle import loss_chain as OL, networks as ON
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    cores = min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     sd_d = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k)
@@ -116,7 +117,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=2)
     args = ap.parse_args()
 
     cfg = CONFIGS[args.config]
@@ -161,7 +162,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = dp.profile_read()
     dp.profile_enable(False)
-    loss_val = float(losses["loss"])
+    loss_val = float(losses["loss"].detach())
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:

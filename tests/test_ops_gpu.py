@@ -62,7 +62,9 @@ def test_ssim(gpu_device, ops_rec):
     pred = torch.from_numpy(ops_rec["ssim/pred"]).to(gpu_device).requires_grad_(True)
     tgt = torch.from_numpy(ops_rec["ssim/target"]).to(gpu_device)
     s = L.SSIM()(pred, tgt)
-    close(s, ops_rec["ssim/out"], 1e-5, 1e-5)
+    # sigma = E[x^2] - mu^2 cancels ~3 digits (0.25 - 0.249): an FMA-contracted sum differs from torch's
+    # by ~3e-8, i.e. ~1e-5 relative on d ~ 2e-3 -> a few 1e-5 on the SSIM value
+    close(s, ops_rec["ssim/out"], 5e-5, 1e-5)
     (s * torch.from_numpy(ops_rec["ssim/cot"]).to(gpu_device)).sum().backward()
     close(pred.grad, ops_rec["ssim/d_pred"], 2e-3, 2e-3)
 
