@@ -2,11 +2,14 @@
 //
 // One launch covers every scale and both source frames of a batch.  A 256-thread workgroup owns a
 // 64x16 pixel tile of one image: 64 lanes run along x so every row access is one coalesced 256-B
-// segment; the 3x3 SSIM window and the smoothness stencil are served from LDS tiles that carry a
-// reflect-padded halo (1 px forward, 2 px backward).  Warped colours are never written to HBM
+// segment, and each lane owns a 4-row strip so the 3x3 SSIM window sums are separable (6 row sums
+// serve 4 pixels).  The 3x3 windows and the smoothness stencil are served from LDS tiles that carry
+// a reflect-padded halo (1 px forward, 2 px backward).  Warped colours are never written to HBM
 // unless the caller asks for the reference's `outputs` tensors; the backward recomputes them.
 // Reductions: wavefront butterfly (64 lanes) -> LDS -> one partial row per workgroup -> a small
 // finalize kernel (deterministic, no float atomics on the loss).
+// Arithmetic: fp32; reciprocals use v_rcp_f32 (1 ulp) instead of IEEE division -- the coordinate
+// noise this adds (~3e-5 px) is the size of the reference's own fp32 rounding.
 //
 // Reference arithmetic restated here (file:line under the reference repo):
 //   F.interpolate bilinear/align_corners=False   vo/learner_new.py:136-140
@@ -19,13 +22,23 @@
 
 namespace {
 
-constexpr int TW = 64, TH = 16, NT = 256, PX = 4;  // tile, threads, pixels per thread
+constexpr int TW = 64, TH = 16, NT = 256, PX = 4;  // tile, threads, rows per lane
 constexpr int FH = TH + 2, FW = TW + 2;            // forward tile + 1-px halo
 constexpr int BH = TH + 4, BW = TW + 4;            // backward tile + 2-px halo
 constexpr int ACC_W = TW / 2 + 4, ACC_H = TH / 2 + 4;  // low-res d_disp footprint of a tile (ratio >= 2)
 constexpr int NPART = 16;                          // forward partial row: 4 scales x {min, sum disp, Gx, Gy}
 constexpr int NDP = 12;                            // dP = d loss / d (K.T)[:3,:4]
 constexpr float C1 = 0.0001f, C2 = 0.0009f;        // SSIM constants, learner_func.py:190-191
+constexpr float K9 = 1.0f / 9.0f;
+#ifndef FWD_WAVES
+#define FWD_WAVES 3   // waves per SIMD the register allocator targets (4 and 3 spill: checked with -Rpass-analysis)
+#endif
+#ifndef BWD_WAVES
+#define BWD_WAVES 2
+#endif
+constexpr int FIELD_ROWS = 6, FIELD_THREADS = FW * (FH / FIELD_ROWS);  // 66 columns x 3 row groups
+static_assert(FH % FIELD_ROWS == 0 && FIELD_THREADS <= NT, "field strips must tile the 1-px-halo tile");
+static_assert(ACC_H * ACC_W <= 3 * FH * FW, "sAcc aliases sF");
 
 struct ChainParams {
     dvs_chain_cfg cfg;
@@ -37,6 +50,8 @@ struct CamMats {
     float iK[9];   // inv_K[:3,:3]
     float P[12];   // (K @ T)[:3,:]
 };
+
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -64,9 +79,9 @@ __device__ __forceinline__ void load_cam(const ChainParams& p, int b, int f, Cam
 }
 
 // Bilinear upsample of a [hs,ws] disparity map to (X,Y) of the [H,W] image, align_corners=False.
-__device__ __forceinline__ float disp_up_at(const float* __restrict__ d, int hs, int ws, int H, int W,
+__device__ __forceinline__ float disp_up_at(const float* __restrict__ d, int hs, int ws, bool same_res, int W,
                                             int X, int Y, float ry, float rx) {
-    if (hs == H && ws == W) return d[Y * W + X];
+    if (same_res) return d[Y * W + X];
     float sy = fmaxf(ry * (Y + 0.5f) - 0.5f, 0.f);
     float sx = fmaxf(rx * (X + 0.5f) - 0.5f, 0.f);
     int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
@@ -77,11 +92,16 @@ __device__ __forceinline__ float disp_up_at(const float* __restrict__ d, int hs,
     return (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
 }
 
+struct Geo {            // per-launch constants of the warp
+    float min_disp, disp_range;
+    float inv_wm1, inv_hm1, wm1, hm1;
+    int H, W;
+};
+
 struct Warp {
     float depth, c0, c1, c2;      // depth and the pixel ray inv_K.[X,Y,1]
-    float den, u, v;              // projective divide
+    float rden, u, v;             // projective divide (rden = 1/(z + eps))
     float gx, gy;                 // normalised grid (Project3D output)
-    float ix, iy;                 // clipped source coordinate
     float mx, my;                 // 1 where the coordinate was NOT clipped (gradient passes)
     int x0, y0;
     float tx, ty;
@@ -89,38 +109,34 @@ struct Warp {
 };
 
 // BackprojectDepth -> Project3D -> grid_sample coordinate, with the reference's operation order.
-__device__ __forceinline__ void warp_geom(const CamMats& m, int X, int Y, float disp_up, float min_disp,
-                                          float disp_range, int H, int W, Warp& w) {
-    float scaled = min_disp + disp_range * disp_up;
-    w.depth = 1.0f / scaled;
+__device__ __forceinline__ void warp_geom(const CamMats& m, const Geo& g, int X, int Y, float disp_up, Warp& w) {
+    w.depth = frcp(g.min_disp + g.disp_range * disp_up);
     float fx = (float)X, fy = (float)Y;
-    w.c0 = fmaf(m.iK[2], 1.f, fmaf(m.iK[1], fy, m.iK[0] * fx));
-    w.c1 = fmaf(m.iK[5], 1.f, fmaf(m.iK[4], fy, m.iK[3] * fx));
-    w.c2 = fmaf(m.iK[8], 1.f, fmaf(m.iK[7], fy, m.iK[6] * fx));
+    w.c0 = fmaf(m.iK[1], fy, m.iK[0] * fx) + m.iK[2];
+    w.c1 = fmaf(m.iK[4], fy, m.iK[3] * fx) + m.iK[5];
+    w.c2 = fmaf(m.iK[7], fy, m.iK[6] * fx) + m.iK[8];
     float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
-    float p0 = fmaf(m.P[3], 1.f, fmaf(m.P[2], Z3, fmaf(m.P[1], Y3, m.P[0] * X3)));
-    float p1 = fmaf(m.P[7], 1.f, fmaf(m.P[6], Z3, fmaf(m.P[5], Y3, m.P[4] * X3)));
-    float p2 = fmaf(m.P[11], 1.f, fmaf(m.P[10], Z3, fmaf(m.P[9], Y3, m.P[8] * X3)));
-    w.den = p2 + 1e-7f;
-    w.u = p0 / w.den;
-    w.v = p1 / w.den;
-    w.gx = (w.u / (float)(W - 1) - 0.5f) * 2.f;
-    w.gy = (w.v / (float)(H - 1) - 0.5f) * 2.f;
-    float ix = ((w.gx + 1.f) * 0.5f) * (float)(W - 1);
-    float iy = ((w.gy + 1.f) * 0.5f) * (float)(H - 1);
-    w.mx = (ix > 0.f && ix < (float)(W - 1)) ? 1.f : 0.f;
-    w.my = (iy > 0.f && iy < (float)(H - 1)) ? 1.f : 0.f;
-    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
-    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
-    w.ix = ix;
-    w.iy = iy;
+    float p0 = fmaf(m.P[2], Z3, fmaf(m.P[1], Y3, m.P[0] * X3)) + m.P[3];
+    float p1 = fmaf(m.P[6], Z3, fmaf(m.P[5], Y3, m.P[4] * X3)) + m.P[7];
+    float p2 = fmaf(m.P[10], Z3, fmaf(m.P[9], Y3, m.P[8] * X3)) + m.P[11];
+    w.rden = frcp(p2 + 1e-7f);
+    w.u = p0 * w.rden;
+    w.v = p1 * w.rden;
+    w.gx = (w.u * g.inv_wm1 - 0.5f) * 2.f;
+    w.gy = (w.v * g.inv_hm1 - 0.5f) * 2.f;
+    float ix = ((w.gx + 1.f) * 0.5f) * g.wm1;
+    float iy = ((w.gy + 1.f) * 0.5f) * g.hm1;
+    w.mx = (ix > 0.f && ix < g.wm1) ? 1.f : 0.f;
+    w.my = (iy > 0.f && iy < g.hm1) ? 1.f : 0.f;
+    ix = fminf(fmaxf(ix, 0.f), g.wm1);
+    iy = fminf(fmaxf(iy, 0.f), g.hm1);
     float x0f = floorf(ix), y0f = floorf(iy);
     w.x0 = (int)x0f;
     w.y0 = (int)y0f;
     w.tx = ix - x0f;
     w.ty = iy - y0f;
-    w.in_x1 = (w.x0 + 1) <= W - 1;
-    w.in_y1 = (w.y0 + 1) <= H - 1;
+    w.in_x1 = (w.x0 + 1) <= g.W - 1;
+    w.in_y1 = (w.y0 + 1) <= g.H - 1;
 }
 
 // Gather the 4 neighbours of one channel plane (out-of-range upper neighbours contribute 0).
@@ -130,9 +146,10 @@ __device__ __forceinline__ void gather4(const float* __restrict__ plane, int W, 
     int dx = w.in_x1 ? 1 : 0;
     int dy = w.in_y1 ? W : 0;
     nw = r0[0];
-    ne = w.in_x1 ? r0[dx] : 0.f;
-    sw = w.in_y1 ? r0[dy] : 0.f;
-    se = (w.in_x1 && w.in_y1) ? r0[dy + dx] : 0.f;
+    float a = r0[dx], b = r0[dy], c = r0[dy + dx];
+    ne = w.in_x1 ? a : 0.f;
+    sw = w.in_y1 ? b : 0.f;
+    se = (w.in_x1 && w.in_y1) ? c : 0.f;
 }
 
 __device__ __forceinline__ float bilerp(const Warp& w, float nw, float ne, float sw, float se) {
@@ -140,55 +157,62 @@ __device__ __forceinline__ float bilerp(const Warp& w, float nw, float ne, float
     return nw * (wx0 * wy0) + ne * (wx1 * wy0) + sw * (wx0 * wy1) + se * (wx1 * wy1);
 }
 
-// SSIM statistics of one channel at window origin (ly,lx) of two LDS tiles with row stride `ld`.
+// Horizontal 3-sums of one window row: x, y, x^2, y^2, xy.
+struct RowSums {
+    float x, y, xx, yy, xy;
+};
+__device__ __forceinline__ RowSums row_sums(const float* __restrict__ xr, const float* __restrict__ yr) {
+    float x0 = xr[0], x1 = xr[1], x2 = xr[2], y0 = yr[0], y1 = yr[1], y2 = yr[2];
+    RowSums r;
+    r.x = x0 + x1 + x2;
+    r.y = y0 + y1 + y2;
+    r.xx = fmaf(x2, x2, fmaf(x1, x1, x0 * x0));
+    r.yy = fmaf(y2, y2, fmaf(y1, y1, y0 * y0));
+    r.xy = fmaf(x2, y2, fmaf(x1, y1, x0 * y0));
+    return r;
+}
+
 struct Stats {
     float mux, muy, sigx, sigy, sigxy;
 };
-__device__ __forceinline__ Stats ssim_stats(const float* __restrict__ x, const float* __restrict__ y, int ld) {
-    float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            float a = x[dy * ld + dx], b = y[dy * ld + dx];
-            sx += a;
-            sy += b;
-            sxx += a * a;
-            syy += b * b;
-            sxy += a * b;
-        }
-    }
+__device__ __forceinline__ Stats stats_of(const RowSums& a, const RowSums& b, const RowSums& c) {
     Stats s;
-    s.mux = sx / 9.f;
-    s.muy = sy / 9.f;
-    s.sigx = sxx / 9.f - s.mux * s.mux;
-    s.sigy = syy / 9.f - s.muy * s.muy;
-    s.sigxy = sxy / 9.f - s.mux * s.muy;
+    s.mux = (a.x + b.x + c.x) * K9;
+    s.muy = (a.y + b.y + c.y) * K9;
+    s.sigx = (a.xx + b.xx + c.xx) * K9 - s.mux * s.mux;
+    s.sigy = (a.yy + b.yy + c.yy) * K9 - s.muy * s.muy;
+    s.sigxy = (a.xy + b.xy + c.xy) * K9 - s.mux * s.muy;
     return s;
 }
 
-__device__ __forceinline__ float ssim_value(const Stats& s) {
-    float n = (2.f * s.mux * s.muy + C1) * (2.f * s.sigxy + C2);
-    float d = (s.mux * s.mux + s.muy * s.muy + C1) * (s.sigx + s.sigy + C2);
-    return (1.f - n / d) * 0.5f;
-}
-
-// ssim_ratio * mean_c SSIM + (1 - ssim_ratio) * mean_c |t - p| at the pixel whose 3x3 window starts at
-// (ly,lx) of the halo tiles (learner_new.py:60-74).
+// ssim_ratio * mean_c SSIM + (1 - ssim_ratio) * mean_c |t - p| (learner_new.py:60-74) for the 4-row strip
+// whose first 3x3 window starts at (ly0, lx) of the halo tiles.
 template <int LD, int PLANE>
-__device__ __forceinline__ float reproj_at(const float* __restrict__ sX, const float* __restrict__ sT, int ly,
-                                           int lx, float ssim_ratio) {
-    float ssim_sum = 0.f, l1_sum = 0.f;
-#pragma unroll
+__device__ __forceinline__ void reproj_strip(const float* __restrict__ sX, const float* __restrict__ sT, int ly0,
+                                             int lx, float ssim_ratio, float out[PX]) {
+    float ssim_sum[PX] = {0.f, 0.f, 0.f, 0.f}, l1_sum[PX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
-        const float* x = sX + c * PLANE + ly * LD + lx;
-        const float* y = sT + c * PLANE + ly * LD + lx;
-        Stats st = ssim_stats(x, y, LD);
-        float v = ssim_value(st);
-        ssim_sum += fminf(fmaxf(v, 0.f), 1.f);
-        l1_sum += fabsf(y[LD + 1] - x[LD + 1]);
+        const float* x = sX + c * PLANE + ly0 * LD + lx;
+        const float* y = sT + c * PLANE + ly0 * LD + lx;
+        RowSums r[PX + 2];
+#pragma unroll
+        for (int j = 0; j < PX + 2; ++j) {
+            r[j] = row_sums(x + j * LD, y + j * LD);
+            if (j >= 1 && j <= PX) l1_sum[j - 1] += fabsf(y[j * LD + 1] - x[j * LD + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            Stats s = stats_of(r[k], r[k + 1], r[k + 2]);
+            float n = (2.f * s.mux * s.muy + C1) * (2.f * s.sigxy + C2);
+            float d = (s.mux * s.mux + s.muy * s.muy + C1) * (s.sigx + s.sigy + C2);
+            float v = (1.f - n * frcp(d)) * 0.5f;
+            ssim_sum[k] += fminf(fmaxf(v, 0.f), 1.f);
+        }
     }
-    return ssim_ratio * (ssim_sum / 3.f) + (1.f - ssim_ratio) * (l1_sum / 3.f);
+#pragma unroll
+    for (int k = 0; k < PX; ++k)
+        out[k] = ssim_ratio * (ssim_sum[k] * (1.f / 3.f)) + (1.f - ssim_ratio) * (l1_sum[k] * (1.f / 3.f));
 }
 
 // ------------------------------------------------------------------------------ counter-based noise
@@ -218,8 +242,29 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n1 = r * s;
 }
 
+__device__ __forceinline__ Geo make_geo(const dvs_chain_cfg& c) {
+    Geo g;
+    g.min_disp = 1.0f / c.max_depth;
+    g.disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
+    g.wm1 = (float)(c.W - 1);
+    g.hm1 = (float)(c.H - 1);
+    g.inv_wm1 = 1.0f / g.wm1;
+    g.inv_hm1 = 1.0f / g.hm1;
+    g.H = c.H;
+    g.W = c.W;
+    return g;
+}
+
+// exp(-mean_c |a - b|) of two pixels of the LDS target tile
+template <int PLANE>
+__device__ __forceinline__ float edge_weight(const float* __restrict__ sT, int o0, int o1) {
+    float gi = fabsf(sT[o0] - sT[o1]) + fabsf(sT[PLANE + o0] - sT[PLANE + o1]) +
+               fabsf(sT[2 * PLANE + o0] - sT[2 * PLANE + o1]);
+    return __expf(-gi * (1.f / 3.f));
+}
+
 // ------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
+__global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p) {
     __shared__ float sT[3 * FH * FW];
     __shared__ float sX[3 * FH * FW];
     __shared__ float sD[FH * FW];
@@ -229,8 +274,9 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
     const int H = c.H, W = c.W, HW = H * W, S = c.num_scales;
     const int b = blockIdx.z, X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const float min_disp = 1.0f / c.max_depth, disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
+    const Geo geo = make_geo(c);
     constexpr int PL = FH * FW;
+    const int X = X0 + tx, Yb = Y0 + PX * ty;      // my strip: column X, rows Yb .. Yb+3
 
     const float* tgt = p.io.target + (size_t)b * 3 * HW;
     for (int i = tid; i < PL; i += NT) {
@@ -240,8 +286,9 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
         for (int ch = 0; ch < 3; ++ch) sT[ch * PL + i] = tgt[ch * HW + gy * W + gx];
     }
 
-    float ident[2][PX];
+    float ident[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (c.auto_mask) {
+#pragma unroll 1
         for (int f = 0; f < 2; ++f) {
             const float* src = p.io.source[f] + (size_t)b * 3 * HW;
             for (int i = tid; i < PL; i += NT) {
@@ -251,40 +298,51 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
                 for (int ch = 0; ch < 3; ++ch) sX[ch * PL + i] = src[ch * HW + gy * W + gx];
             }
             __syncthreads();
+            {
+                float tmp[PX];
+                reproj_strip<FW, PL>(sX, sT, PX * ty, tx, c.ssim_ratio, tmp);
 #pragma unroll
-            for (int k = 0; k < PX; ++k) ident[f][k] = reproj_at<FW, PL>(sX, sT, ty + 4 * k, tx, c.ssim_ratio);
+                for (int k = 0; k < PX; ++k) {   // static indices only: a runtime-indexed array would live in scratch
+                    ident[0][k] = (f == 0) ? tmp[k] : ident[0][k];
+                    ident[1][k] = (f == 1) ? tmp[k] : ident[1][k];
+                }
+            }
             __syncthreads();
         }
     } else {
         __syncthreads();
     }
 
-    float acc[DVS_MAX_SCALES][4];
-#pragma unroll
-    for (int s = 0; s < DVS_MAX_SCALES; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[s][j] = 0.f;
     uint32_t selbits[PX] = {0, 0, 0, 0};
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid < NPART) sRed[0][tid] = sRed[1][tid] = sRed[2][tid] = sRed[3][tid] = 0.f;
 
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
         const int hs = c.hs[s], ws = c.ws[s];
+        const bool same_res = (hs == H && ws == W);
         const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
         const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
-        float rp[2][PX];
+        float rp[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float a_min = 0.f, a_disp = 0.f, a_gx = 0.f, a_gy = 0.f;   // this scale's partial sums
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {
             CamMats m;
             load_cam(p, b, f, m);
             const float* src = p.io.source[f] + (size_t)b * 3 * HW;
+            float* o_color = p.io.color[s][f];
+            float* o_grid = p.io.grid[s][f];
+            float* o_dup = (f == 0) ? p.io.disp_up[s] : nullptr;
+            float* o_depth = (f == 0) ? p.io.depth[s] : nullptr;
+            const bool materialize = o_color || o_grid || o_dup || o_depth;
             for (int i = tid; i < PL; i += NT) {
                 int hy = i / FW, hx = i - hy * FW;
                 int px = X0 - 1 + hx, py = Y0 - 1 + hy;
                 int gx = reflect_idx(px, W), gy = reflect_idx(py, H);
-                float du = disp_up_at(dsp, hs, ws, H, W, gx, gy, ry, rx);
+                float du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
                 if (f == 0) sD[i] = du;
                 Warp w;
-                warp_geom(m, gx, gy, du, min_disp, disp_range, H, W, w);
+                warp_geom(m, geo, gx, gy, du, w);
                 float col[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -294,33 +352,37 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
                     sX[ch * PL + i] = col[ch];
                 }
                 // optional materialisation of the reference's `outputs` tensors (interior pixels only)
-                bool interior = hx >= 1 && hx <= TW && hy >= 1 && hy <= TH && px < W && py < H;
-                if (interior) {
+                if (materialize && hx >= 1 && hx <= TW && hy >= 1 && hy <= TH && px < W && py < H) {
                     size_t o = (size_t)b * HW + (size_t)py * W + px;
-                    if (p.io.color[s][f]) {
+                    if (o_color) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch)
-                            p.io.color[s][f][(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)py * W + px] = col[ch];
+                            o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)py * W + px] = col[ch];
                     }
-                    if (p.io.grid[s][f]) {
-                        p.io.grid[s][f][o * 2 + 0] = w.gx;
-                        p.io.grid[s][f][o * 2 + 1] = w.gy;
+                    if (o_grid) {
+                        o_grid[o * 2 + 0] = w.gx;
+                        o_grid[o * 2 + 1] = w.gy;
                     }
-                    if (f == 0) {
-                        if (p.io.disp_up[s]) p.io.disp_up[s][o] = du;
-                        if (p.io.depth[s]) p.io.depth[s][o] = w.depth;
-                    }
+                    if (o_dup) o_dup[o] = du;
+                    if (o_depth) o_depth[o] = w.depth;
                 }
             }
             __syncthreads();
+            {
+                float tmp[PX];
+                reproj_strip<FW, PL>(sX, sT, PX * ty, tx, c.ssim_ratio, tmp);
 #pragma unroll
-            for (int k = 0; k < PX; ++k) rp[f][k] = reproj_at<FW, PL>(sX, sT, ty + 4 * k, tx, c.ssim_ratio);
+                for (int k = 0; k < PX; ++k) {
+                    rp[0][k] = (f == 0) ? tmp[k] : rp[0][k];
+                    rp[1][k] = (f == 1) ? tmp[k] : rp[1][k];
+                }
+            }
             __syncthreads();
         }
 
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
-            int X = X0 + tx, Y = Y0 + ty + 4 * k;
+            int Y = Yb + k;
             if (X >= W || Y >= H) continue;
             // 4-way min with first-minimum-wins ties; candidates 0,1 = identity(-1,+1), 2,3 = reprojection(-1,+1)
             float best = rp[0][k];
@@ -345,46 +407,38 @@ __global__ __launch_bounds__(NT) void chain_fwd_kernel(ChainParams p) {
                 if (rp[0][k] < best) { best = rp[0][k]; idx = 2; }
             }
             if (rp[1][k] < best) { best = rp[1][k]; idx = 3; }
-            acc[s][0] += best;
+            a_min += best;
             selbits[k] |= idx << (2 * s);
 
             // smoothness partial sums on the un-normalised disparity (the per-image mean divides out
             // in the finalize kernel): learner_new.py:246-250, learner_func.py:161-174
-            int ly = ty + 4 * k + 1, lx = tx + 1;
-            float d0 = sD[ly * FW + lx];
-            acc[s][1] += d0;
-            if (X < W - 1) {
-                float gi = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) gi += fabsf(sT[ch * PL + ly * FW + lx] - sT[ch * PL + ly * FW + lx + 1]);
-                acc[s][2] += fabsf(d0 - sD[ly * FW + lx + 1]) * __expf(-gi / 3.f);
-            }
-            if (Y < H - 1) {
-                float gi = 0.f;
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) gi += fabsf(sT[ch * PL + ly * FW + lx] - sT[ch * PL + (ly + 1) * FW + lx]);
-                acc[s][3] += fabsf(d0 - sD[(ly + 1) * FW + lx]) * __expf(-gi / 3.f);
-            }
+            int o = (PX * ty + k + 1) * FW + tx + 1;
+            float d0 = sD[o];
+            a_disp += d0;
+            if (X < W - 1) a_gx += fabsf(d0 - sD[o + 1]) * edge_weight<PL>(sT, o, o + 1);
+            if (Y < H - 1) a_gy += fabsf(d0 - sD[o + FW]) * edge_weight<PL>(sT, o, o + FW);
+        }
+        // wave butterfly now, workgroup sum after the scale loop
+        a_min = dvs::wave_sum(a_min);
+        a_disp = dvs::wave_sum(a_disp);
+        a_gx = dvs::wave_sum(a_gx);
+        a_gy = dvs::wave_sum(a_gy);
+        if (lane == 0) {
+            sRed[wave][s * 4 + 0] = a_min;
+            sRed[wave][s * 4 + 1] = a_disp;
+            sRed[wave][s * 4 + 2] = a_gx;
+            sRed[wave][s * 4 + 3] = a_gy;
         }
         __syncthreads();  // sD / sX are rewritten by the next scale
     }
 
 #pragma unroll
     for (int k = 0; k < PX; ++k) {
-        int X = X0 + tx, Y = Y0 + ty + 4 * k;
+        int Y = Yb + k;
         if (X < W && Y < H) p.io.sel[(size_t)b * HW + (size_t)Y * W + X] = (uint8_t)selbits[k];
     }
 
-    // workgroup reduction: wave butterfly -> LDS -> 16 lanes
-    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-    for (int s = 0; s < DVS_MAX_SCALES; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v = dvs::wave_sum(acc[s][j]);
-            if (lane == 0) sRed[wave][s * 4 + j] = v;
-        }
-    __syncthreads();
+    // workgroup reduction: per-wave sums sit in LDS -> 16 lanes
     if (tid < NPART) {
         float v = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
         int tile = blockIdx.y * p.tiles_x + blockIdx.x;
@@ -438,23 +492,24 @@ struct BwdParams {
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams q) {
+__global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p, BwdParams q) {
     __shared__ float sT[3 * BH * BW];
     __shared__ float sX[3 * BH * BW];
     __shared__ float sD[BH * BW];
-    __shared__ float sF[3 * FH * FW];
+    __shared__ float sF[3 * FH * FW];     // SSIM derivative fields of one channel; reused as sAcc
     __shared__ uint8_t sSel[FH * FW];
-    __shared__ float sAcc[ACC_H * ACC_W];
     __shared__ float sRed[NT / 64][NDP];
+    float* sAcc = sF;
 
     const dvs_chain_cfg& c = p.cfg;
     const int H = c.H, W = c.W, HW = H * W, S = c.num_scales;
     const int b = blockIdx.z, X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int wave = tid >> 6, lane = tid & 63;
-    const float min_disp = 1.0f / c.max_depth, disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
+    const Geo geo = make_geo(c);
     constexpr int PLB = BH * BW, PLF = FH * FW;
     const int tile = blockIdx.y * p.tiles_x + blockIdx.x, ntiles = p.tiles_x * p.tiles_y;
+    const int X = X0 + tx, Yb = Y0 + PX * ty;      // my strip: column X, rows Yb .. Yb+3
 
     const float* tgt = p.io.target + (size_t)b * 3 * HW;
     for (int i = tid; i < PLB; i += NT) {
@@ -467,6 +522,8 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
         int hy = i / FW, hx = i - hy * FW;
         int px = X0 - 1 + hx, py = Y0 - 1 + hy;
         bool in = px >= 0 && px < W && py >= 0 && py < H;
+        // pixels outside the image never match a frame id (0xFF -> every 2-bit field is 3 only if stored so;
+        // use a separate validity test below instead)
         sSel[i] = in ? p.io.sel[(size_t)b * HW + (size_t)py * W + px] : (uint8_t)0;
     }
     __syncthreads();
@@ -474,6 +531,13 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
     const float w_pix = 1.0f / ((float)c.B * (float)HW);
     const float cx = 1.0f / ((float)c.B * (float)H * (float)(W - 1));
     const float cy = 1.0f / ((float)c.B * (float)(H - 1) * (float)W);
+    // ReflectionPad2d(1): the window of border pixel 0 (W-1) reads column 1 (W-2) twice
+    const float wxm = (X == 1) ? 2.f : 1.f, wxp = (X == W - 2) ? 2.f : 1.f;
+
+    // field strip owned by this thread: column fcol, rows frow0 .. frow0+5 of the 1-px-halo tile
+    const int fcol = tid % FW, frow0 = (tid / FW) * FIELD_ROWS;
+    const bool field_thread = tid < FIELD_THREADS;
+    const int fpx = X0 - 1 + fcol;
 
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
@@ -482,11 +546,9 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
         const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
         const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
         const float gl = q.g.d_losses[s];
-        const float w_ssim = gl * w_pix * c.ssim_ratio / 3.f * (-0.5f) / 9.f;
-        const float w_l1 = gl * w_pix * (1.f - c.ssim_ratio) / 3.f;
+        const float w_ssim = gl * w_pix * c.ssim_ratio * (1.f / 3.f) * (-0.5f) * K9;
+        const float w_l1 = gl * w_pix * (1.f - c.ssim_ratio) * (1.f / 3.f);
         float gd[PX] = {0.f, 0.f, 0.f, 0.f};  // d loss / d disp_up at my pixels
-
-        for (int i = tid; i < ACC_H * ACC_W; i += NT) sAcc[i] = 0.f;
 
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {
@@ -497,10 +559,10 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
             for (int i = tid; i < PLB; i += NT) {
                 int hy = i / BW, hx = i - hy * BW;
                 int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
-                float du = disp_up_at(dsp, hs, ws, H, W, gx, gy, ry, rx);
+                float du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
                 if (f == 0) sD[i] = du;
                 Warp w;
-                warp_geom(m, gx, gy, du, min_disp, disp_range, H, W, w);
+                warp_geom(m, geo, gx, gy, du, w);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     float nw, ne, sw, se;
@@ -511,62 +573,66 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
             __syncthreads();
 
             float dcol[PX][3];
-#pragma unroll
-            for (int k = 0; k < PX; ++k) dcol[k][0] = dcol[k][1] = dcol[k][2] = 0.f;
-
 #pragma unroll 1
             for (int ch = 0; ch < 3; ++ch) {
                 // SSIM derivative coefficient fields at every pixel p of tile + 1-px halo:
                 // d out / d x(r) = -1/2 * 1/9 * (alpha(p) + beta(p) x(r) + gamma(p) y(r)) for r in window(p)
-                for (int i = tid; i < PLF; i += NT) {
-                    int hy = i / FW, hx = i - hy * FW;
-                    int px = X0 - 1 + hx, py = Y0 - 1 + hy;
-                    float fa = 0.f, fb = 0.f, fc = 0.f;
-                    bool in = px >= 0 && px < W && py >= 0 && py < H;
-                    if (in && ((sSel[i] >> (2 * s)) & 3u) == want) {
-                        Stats st = ssim_stats(sX + ch * PLB + hy * BW + hx, sT + ch * PLB + hy * BW + hx, BW);
-                        float n1 = 2.f * st.mux * st.muy + C1, n2 = 2.f * st.sigxy + C2;
-                        float d1 = st.mux * st.mux + st.muy * st.muy + C1, d2 = st.sigx + st.sigy + C2;
-                        float d = d1 * d2, R = (n1 * n2) / d;
-                        float v = (1.f - R) * 0.5f;
-                        if (v >= 0.f && v <= 1.f) {
-                            float dR_dmux = 2.f * st.muy * n2 / d - R * 2.f * st.mux / d1;
-                            float dR_dsx = -R / d2;
-                            float dR_dsxy = 2.f * n1 / d;
-                            fa = w_ssim * (dR_dmux - 2.f * st.mux * dR_dsx - st.muy * dR_dsxy);
-                            fb = w_ssim * 2.f * dR_dsx;
-                            fc = w_ssim * dR_dsxy;
+                if (field_thread) {
+                    const float* xw = sX + ch * PLB + frow0 * BW + fcol;
+                    const float* yw = sT + ch * PLB + frow0 * BW + fcol;
+                    RowSums r0 = row_sums(xw, yw), r1 = row_sums(xw + BW, yw + BW);
+#pragma unroll
+                    for (int j = 0; j < FIELD_ROWS; ++j) {
+                        RowSums r2 = row_sums(xw + (j + 2) * BW, yw + (j + 2) * BW);
+                        int hy = frow0 + j, i = hy * FW + fcol, py = Y0 - 1 + hy;
+                        float fa = 0.f, fb = 0.f, fc = 0.f;
+                        bool in = fpx >= 0 && fpx < W && py >= 0 && py < H;
+                        if (in && ((sSel[i] >> (2 * s)) & 3u) == want) {
+                            Stats st = stats_of(r0, r1, r2);
+                            float n1 = 2.f * st.mux * st.muy + C1, n2 = 2.f * st.sigxy + C2;
+                            float d1 = st.mux * st.mux + st.muy * st.muy + C1, d2 = st.sigx + st.sigy + C2;
+                            float rd1 = frcp(d1), rd2 = frcp(d2), rd = rd1 * rd2;
+                            float R = n1 * n2 * rd, v = (1.f - R) * 0.5f;
+                            if (v >= 0.f && v <= 1.f) {
+                                float dR_dmux = 2.f * st.muy * n2 * rd - R * 2.f * st.mux * rd1;
+                                float dR_dsx = -R * rd2;
+                                float dR_dsxy = 2.f * n1 * rd;
+                                fa = w_ssim * (dR_dmux - 2.f * st.mux * dR_dsx - st.muy * dR_dsxy);
+                                fb = w_ssim * 2.f * dR_dsx;
+                                fc = w_ssim * dR_dsxy;
+                            }
                         }
+                        sF[0 * PLF + i] = fa;
+                        sF[1 * PLF + i] = fb;
+                        sF[2 * PLF + i] = fc;
+                        r0 = r1;
+                        r1 = r2;
                     }
-                    sF[0 * PLF + i] = fa;
-                    sF[1 * PLF + i] = fb;
-                    sF[2 * PLF + i] = fc;
                 }
                 __syncthreads();
+                {
+                    // separable 3x3 gather of the three fields for my 4-row strip (rows PX*ty .. +5 of sF)
+                    float ha[PX + 2], hb[PX + 2], hc[PX + 2];
 #pragma unroll
-                for (int k = 0; k < PX; ++k) {
-                    int X = X0 + tx, Y = Y0 + ty + 4 * k;
-                    if (X >= W || Y >= H) continue;
-                    int ly = ty + 4 * k + 1, lx = tx + 1;  // position in the 1-halo field tile
-                    float Sa = 0.f, Sb = 0.f, Sc = 0.f;
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy) {
-                        // ReflectionPad2d(1): the window of border pixel 0 (H-1) reads row 1 (H-2) twice
-                        float wy = 1.f + ((Y == 1 && dy == -1) ? 1.f : 0.f) + ((Y == H - 2 && dy == 1) ? 1.f : 0.f);
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            float wx = 1.f + ((X == 1 && dx == -1) ? 1.f : 0.f) + ((X == W - 2 && dx == 1) ? 1.f : 0.f);
-                            int o = (ly + dy) * FW + lx + dx;
-                            float ww = wx * wy;
-                            Sa += ww * sF[0 * PLF + o];
-                            Sb += ww * sF[1 * PLF + o];
-                            Sc += ww * sF[2 * PLF + o];
-                        }
+                    for (int j = 0; j < PX + 2; ++j) {
+                        int o = (PX * ty + j) * FW + tx;
+                        ha[j] = wxm * sF[o] + sF[o + 1] + wxp * sF[o + 2];
+                        hb[j] = wxm * sF[PLF + o] + sF[PLF + o + 1] + wxp * sF[PLF + o + 2];
+                        hc[j] = wxm * sF[2 * PLF + o] + sF[2 * PLF + o + 1] + wxp * sF[2 * PLF + o + 2];
                     }
-                    float xq = sX[ch * PLB + (ly + 1) * BW + lx + 1], yq = sT[ch * PLB + (ly + 1) * BW + lx + 1];
-                    float g = Sa + Sb * xq + Sc * yq;
-                    if (((sSel[ly * FW + lx] >> (2 * s)) & 3u) == want) g += w_l1 * sgn(xq - yq);
-                    dcol[k][ch] = g;
+#pragma unroll
+                    for (int k = 0; k < PX; ++k) {
+                        int Y = Yb + k;
+                        float wym = (Y == 1) ? 2.f : 1.f, wyp = (Y == H - 2) ? 2.f : 1.f;
+                        float Sa = wym * ha[k] + ha[k + 1] + wyp * ha[k + 2];
+                        float Sb = wym * hb[k] + hb[k + 1] + wyp * hb[k + 2];
+                        float Sc = wym * hc[k] + hc[k + 1] + wyp * hc[k + 2];
+                        int o2 = (PX * ty + k + 2) * BW + tx + 2;
+                        float xq = sX[ch * PLB + o2], yq = sT[ch * PLB + o2];
+                        float g = Sa + Sb * xq + Sc * yq;
+                        if (((sSel[(PX * ty + k + 1) * FW + tx + 1] >> (2 * s)) & 3u) == want) g += w_l1 * sgn(xq - yq);
+                        dcol[k][ch] = g;
+                    }
                 }
                 __syncthreads();
             }
@@ -577,11 +643,11 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
             for (int j = 0; j < NDP; ++j) dP[j] = 0.f;
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
-                float du = sD[(ty + 4 * k + 2) * BW + tx + 2];
+                float du = sD[(PX * ty + k + 2) * BW + tx + 2];
                 Warp w;
-                warp_geom(m, X, Y, du, min_disp, disp_range, H, W, w);
+                warp_geom(m, geo, X, Y, du, w);
                 float gix = 0.f, giy = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -593,8 +659,8 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
                 }
                 // d ix / d u = mask (the (W-1)/2 and 2/(W-1) factors of unnormalise/normalise cancel)
                 float d_u = gix * w.mx, d_v = giy * w.my;
-                float dp0 = d_u / w.den, dp1 = d_v / w.den;
-                float dp2 = -(d_u * w.u + d_v * w.v) / w.den;
+                float dp0 = d_u * w.rden, dp1 = d_v * w.rden;
+                float dp2 = -(d_u * w.u + d_v * w.v) * w.rden;
                 float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
                 dP[0] += dp0 * X3; dP[1] += dp0 * Y3; dP[2] += dp0 * Z3; dP[3] += dp0;
                 dP[4] += dp1 * X3; dP[5] += dp1 * Y3; dP[6] += dp1 * Z3; dP[7] += dp1;
@@ -603,7 +669,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
                 float dc1 = m.P[1] * dp0 + m.P[5] * dp1 + m.P[9] * dp2;
                 float dc2 = m.P[2] * dp0 + m.P[6] * dp1 + m.P[10] * dp2;
                 float d_depth = dc0 * w.c0 + dc1 * w.c1 + dc2 * w.c2;
-                gd[k] += d_depth * (-w.depth * w.depth * disp_range);
+                gd[k] += d_depth * (-w.depth * w.depth * geo.disp_range);
             }
 #pragma unroll
             for (int j = 0; j < NDP; ++j) {
@@ -629,22 +695,15 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
             float k_mean = (mean_raw >= 0.001f) ? -gs * (cx * st[2] + cy * st[3]) / (mean * mean) / hw : 0.f;
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
-                int ly = ty + 4 * k + 2, lx = tx + 2;
-                float d0 = sD[ly * BW + lx];
+                int o = (PX * ty + k + 2) * BW + tx + 2;
+                float d0 = sD[o];
                 float g = 0.f;
-                auto img_w = [&](int oy0, int ox0, int oy1, int ox1) {
-                    float gi = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch)
-                        gi += fabsf(sT[ch * PLB + (ly + oy0) * BW + lx + ox0] - sT[ch * PLB + (ly + oy1) * BW + lx + ox1]);
-                    return __expf(-gi / 3.f);
-                };
-                if (X < W - 1) g += cx * sgn(d0 - sD[ly * BW + lx + 1]) * img_w(0, 0, 0, 1);
-                if (X > 0) g -= cx * sgn(sD[ly * BW + lx - 1] - d0) * img_w(0, -1, 0, 0);
-                if (Y < H - 1) g += cy * sgn(d0 - sD[(ly + 1) * BW + lx]) * img_w(0, 0, 1, 0);
-                if (Y > 0) g -= cy * sgn(sD[(ly - 1) * BW + lx] - d0) * img_w(-1, 0, 0, 0);
+                if (X < W - 1) g += cx * sgn(d0 - sD[o + 1]) * edge_weight<PLB>(sT, o, o + 1);
+                if (X > 0) g -= cx * sgn(sD[o - 1] - d0) * edge_weight<PLB>(sT, o - 1, o);
+                if (Y < H - 1) g += cy * sgn(d0 - sD[o + BW]) * edge_weight<PLB>(sT, o, o + BW);
+                if (Y > 0) g -= cy * sgn(sD[o - BW] - d0) * edge_weight<PLB>(sT, o - BW, o);
                 gd[k] += k_grad * g + k_mean;
             }
         }
@@ -654,16 +713,18 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
         if (same_res) {
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                int Y = Yb + k;
                 if (X < W && Y < H) dd[Y * W + X] = gd[k];
             }
         } else {
-            // low-res footprint origin of this tile
-            int ox = max((int)fmaxf(rx * (X0 + 0.5f) - 0.5f, 0.f), 0), oy = max((int)fmaxf(ry * (Y0 + 0.5f) - 0.5f, 0.f), 0);
-            __syncthreads();  // sAcc zero-fill visible
+            // accumulate the tile's low-res footprint in LDS (sAcc aliases sF: the frame loop has ended),
+            // then one global atomic per touched low-res pixel
+            for (int i = tid; i < ACC_H * ACC_W; i += NT) sAcc[i] = 0.f;
+            int ox = (int)fmaxf(rx * (X0 + 0.5f) - 0.5f, 0.f), oy = (int)fmaxf(ry * (Y0 + 0.5f) - 0.5f, 0.f);
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
-                int X = X0 + tx, Y = Y0 + ty + 4 * k;
+                int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
                 float sy = fmaxf(ry * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(rx * (X + 0.5f) - 0.5f, 0.f);
                 int y0 = min((int)sy, hs - 1), x0 = min((int)sx, ws - 1);
@@ -683,7 +744,7 @@ __global__ __launch_bounds__(NT) void chain_bwd_kernel(ChainParams p, BwdParams 
                 if (v != 0.f && yy < hs && xx < ws) atomicAdd(&dd[yy * ws + xx], v);
             }
         }
-        __syncthreads();  // sD, sAcc reused by the next scale
+        __syncthreads();  // sD, sF/sAcc reused by the next scale
     }
 }
 
