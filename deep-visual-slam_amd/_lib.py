@@ -41,7 +41,18 @@ class ChainBwdIO(C.Structure):
                 ("bwd_partials", _vp)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int)]
+
+
+class ConvFusion(C.Structure):
+    _fields_ = [("x2", _vp), ("C1", C.c_int), ("in_scale", _vp), ("in_shift", _vp), ("in_relu", C.c_int),
+                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp)]
+
+
 _SIGNATURES = {
+    "dvs_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),

@@ -1,0 +1,181 @@
+// Shared device code of the implicit-GEMM convolution kernels (conv_fwd.hip, conv_bwd.hip).
+//
+// Data layout (HBM): activations NHWC fp32 (torch "channels_last": logical [B,C,H,W]); weights
+// [Cout][kh][kw][Cin] fp32 (torch channels_last of the reference's [Cout,Cin,kh,kw] parameter), i.e. a
+// row-major [N][K] matrix with K = (kh,kw,ci) contiguous -- exactly the im2col K order.
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles / instruction / SIMD = the fp32 peak).
+// LDS tiles are [rows][BK + 4] floats: the 16-byte row pad makes ds_read_b128 conflict-free (slot index
+// 9*row mod 16 is a permutation).  Each lane fetches 4 consecutive k per read; the MFMA's two k-slots
+// (lane halves) are mapped to k = 8j + 4h + t, the same permutation for A and B, so the sum is exact.
+//
+// Gathers are branch-free: every lane always issues its 16-byte load from a clamped (always valid)
+// address and the padding / tail zeros are selected afterwards, so the loads of a stage go out back to
+// back instead of being serialised behind exec-mask branches.
+#pragma once
+#include "common.h"
+
+namespace dvsconv {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;          // k per LDS stage
+constexpr int LDK = BK + 4;     // padded LDS row (floats)
+constexpr int NT = 256;         // 4 waves
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
+enum Pad { PAD_ZERO = 0, PAD_REFLECT = 1 };
+// how the logical input is stored
+enum InMode {
+    IN_NHWC = 0,     // one NHWC tensor
+    IN_UPCAT = 1,    // concat(upsample_nearest2x(x [B,H/2,W/2,C1]), x2 [B,H,W,Cin-C1])  (model/depthnet.py:81-85)
+    IN_PLANAR = 2    // planar [B,Cin,H,W] image, K ordered (ci,ky,kx8): encoder conv1 (model/resnet_encoder.py:102-103)
+};
+
+struct ConvShape {
+    int B, H, W, Cin;        // logical input  [B,H,W,Cin]
+    int Ho, Wo, Cout;        // output [B,Ho,Wo,Cout]
+    int kh, kw, stride, pad; // pad = implicit padding on each side (zero or reflect)
+    int pad_mode;
+    int Ktot;                // GEMM K: kh*kw*Cin (IN_PLANAR: Cin*kh*8 with kw padded to 8)
+};
+
+struct InXform {
+    const float* x2;
+    int C1;
+    const float* in_scale;   // per-channel affine (folded BatchNorm, or the input normalisation) ...
+    const float* in_shift;
+    int in_relu;             // ... followed by ReLU
+};
+
+__device__ __forceinline__ int reflect_i(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+__device__ __forceinline__ int clampi(int i, int n) { return min(max(i, 0), n - 1); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_ELU: return v > 0.f ? v : expm1f(v);
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-position iterator: decodes the stage's k = kt*32 + c4 into (tap ky,kx ; channel ci) incrementally.
+// ---------------------------------------------------------------------------------------------
+struct KPos {
+    int k, ci, ky, kx;
+    __device__ __forceinline__ void init(int c4, const ConvShape& s) {
+        k = c4;
+        int tap = c4 / s.Cin;
+        ci = c4 - tap * s.Cin;
+        ky = tap / s.kw;
+        kx = tap - ky * s.kw;
+    }
+    __device__ __forceinline__ void advance(const ConvShape& s) {
+        k += BK;
+        ci += BK;
+        while (ci >= s.Cin) {
+            ci -= s.Cin;
+            if (++kx == s.kw) {
+                kx = 0;
+                ++ky;
+            }
+        }
+    }
+};
+
+// One 16-byte slice (4 channels at ci) of input pixel (b, iy, ix); `ok` folds row validity and k < Ktot.
+template <int MODE, bool FOLD>
+__device__ __forceinline__ f32x4 gather4(const float* __restrict__ x, const ConvShape& s, const InXform& t, int b,
+                                         int iy, int ix, int ci, bool ok) {
+    if (s.pad_mode == PAD_REFLECT) {
+        iy = reflect_i(iy, s.H);
+        ix = reflect_i(ix, s.W);
+    } else {
+        ok = ok && (unsigned)iy < (unsigned)s.H && (unsigned)ix < (unsigned)s.W;
+    }
+    iy = clampi(iy, s.H);
+    ix = clampi(ix, s.W);
+    f32x4 v;
+    if (MODE == IN_UPCAT) {
+        if (ci < t.C1) {     // block-uniform: C1 is a multiple of the 32-channel stage
+            int h2 = s.H >> 1, w2 = s.W >> 1;
+            v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * h2 + (iy >> 1)) * w2 + (ix >> 1)) * t.C1 + ci);
+        } else {
+            int c2 = s.Cin - t.C1;
+            v = *reinterpret_cast<const f32x4*>(t.x2 + (((size_t)b * s.H + iy) * s.W + ix) * c2 + (ci - t.C1));
+        }
+    } else {
+        v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * s.H + iy) * s.W + ix) * s.Cin + ci);
+    }
+    if (FOLD) {
+        f32x4 sc = *reinterpret_cast<const f32x4*>(t.in_scale + ci);
+        f32x4 sh = *reinterpret_cast<const f32x4*>(t.in_shift + ci);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = v[j] * sc[j] + sh[j];
+            v[j] = t.in_relu ? fmaxf(u, 0.f) : u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+    return v;
+}
+
+// IN_PLANAR: k = (ci*kh + ky)*8 + kx (kx padded to 8); a 16-byte k-slice is 4 horizontally adjacent
+// pixels of one planar channel row.
+template <bool FOLD>
+__device__ __forceinline__ f32x4 gather4_planar(const float* __restrict__ x, const ConvShape& s, const InXform& t,
+                                                int b, int iy0, int ix0, int k, bool ok) {
+    int kx = k & 7, row = k >> 3;
+    int ci = row / s.kh, ky = row - ci * s.kh;
+    ci = min(ci, s.Cin - 1);
+    int iy = iy0 + ky;
+    bool oky = ok && (unsigned)iy < (unsigned)s.H;
+    const float* rowp = x + (((size_t)b * s.Cin + ci) * s.H + clampi(iy, s.H)) * s.W;
+    float sc = 1.f, sh = 0.f;
+    if (FOLD) {
+        sc = t.in_scale[ci];
+        sh = t.in_shift[ci];
+    }
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int ix = ix0 + kx + e;
+        float u = rowp[clampi(ix, s.W)];
+        if (FOLD) u = u * sc + sh;
+        v[e] = (oky && (unsigned)ix < (unsigned)s.W && kx + e < s.kw) ? u : 0.f;
+    }
+    return v;
+}
+
+// One BK-deep MFMA pass over LDS tiles As[BM][LDK], Bs[BN][LDK] for a wave that owns TM x TN 32x32 tiles
+// starting at rows a_row0 / b_row0.  lane = threadIdx.x & 63.
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const float* __restrict__ Bs, int a_row0,
+                                           int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+            a[m] = *reinterpret_cast<const f32x4*>(As + (a_row0 + m * 32 + r) * LDK + j * 8 + h * 4);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+            b[n] = *reinterpret_cast<const f32x4*>(Bs + (b_row0 + n * 32 + r) * LDK + j * 8 + h * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+    }
+}
+
+}  // namespace dvsconv

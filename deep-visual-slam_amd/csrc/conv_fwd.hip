@@ -1,0 +1,239 @@
+// a1-a3: forward convolution as an implicit GEMM on the fp32 matrix cores of gfx950.
+//
+//   Y[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ),   m = (b,oy,ox), n = co, k = (kh,kw,ci)
+//
+// A is never materialised: the workgroup gathers its BM x 32 slice of the im2col matrix straight from
+// the NHWC activation (16-byte vectors of 4 channels; zero or reflection padding, the decoder's
+// nearest-upsample + skip concat, a folded BatchNorm+ReLU of the producer, or the encoder's input
+// normalisation are applied in that gather), stages it and the [BN][32] weight slice in LDS (double
+// buffered, one barrier per K-step) and runs v_mfma_f32_32x32x2_f32 on 32x32 sub-tiles.
+// Epilogue: bias, ReLU/ELU/sigmoid, optional per-channel sum / sum-of-squares of the raw output (the
+// batch statistics nn.BatchNorm2d needs in training mode), NHWC store (128-B segments per half wave).
+//
+// Replaces nn.Conv2d / Conv3x3 / ConvBlock forward of model/resnet_encoder.py:100-111 (torchvision
+// BasicBlock convs), model/depthnet.py:64-90, model/layers.py:106-136, model/posenet_single.py:174-202.
+#include "conv_common.h"
+
+namespace {
+using namespace dvsconv;
+
+struct FwdParams {
+    const float* x;
+    const float* w;      // [Cout][Ktot]
+    const float* bias;   // [Cout] or NULL
+    float* y;            // [B,Ho,Wo,Cout]
+    float* stats;        // [2][Cout] running sum / sum of squares of the raw output, or NULL
+    ConvShape s;
+    InXform t;
+    int act;
+};
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+__global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_VECS = BM / 32, B_VECS = BN / 32;       // 16-byte vectors per thread per stage
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;                // [2][BN][LDK]
+
+    const ConvShape& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = s.B * s.Ho * s.Wo;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int c4 = (tid & 7) * 4, r0 = tid >> 3;            // my k-offset inside a stage, my first row
+
+    // output pixels of my A rows
+    int a_b[A_VECS], a_iy[A_VECS], a_ix[A_VECS];
+    bool a_ok[A_VECS];
+#pragma unroll
+    for (int j = 0; j < A_VECS; ++j) {
+        int m = m0 + r0 + 32 * j;
+        a_ok[j] = m < M;
+        m = min(m, M - 1);
+        int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+        int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+        a_b[j] = b;
+        a_iy[j] = oy * s.stride - s.pad;
+        a_ix[j] = ox * s.stride - s.pad;
+    }
+    // weight rows
+    const float* b_ptr[B_VECS];
+    bool b_ok[B_VECS];
+#pragma unroll
+    for (int j = 0; j < B_VECS; ++j) {
+        int n = n0 + r0 + 32 * j;
+        b_ok[j] = n < s.Cout;
+        b_ptr[j] = p.w + (size_t)min(n, s.Cout - 1) * s.Ktot;
+    }
+
+    KPos kp;
+    kp.init(c4, s);
+    f32x4 ra[A_VECS], rb[B_VECS];
+    auto load_stage = [&]() {      // loads the stage kp points at, then advances kp
+        const bool k_ok = kp.k < s.Ktot;
+        const int kc = min(kp.k, s.Ktot - 4);
+#pragma unroll
+        for (int j = 0; j < A_VECS; ++j) {
+            if (MODE == IN_PLANAR)
+                ra[j] = gather4_planar<FOLD>(p.x, s, p.t, a_b[j], a_iy[j], a_ix[j], kc, a_ok[j] && k_ok);
+            else
+                ra[j] = gather4<MODE, FOLD>(p.x, s, p.t, a_b[j], a_iy[j] + kp.ky, a_ix[j] + kp.kx, kp.ci,
+                                            a_ok[j] && k_ok);
+        }
+#pragma unroll
+        for (int j = 0; j < B_VECS; ++j) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(b_ptr[j] + kc);
+            const bool ok = b_ok[j] && k_ok;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[j][e] = ok ? v[e] : 0.f;
+        }
+        if (MODE == IN_PLANAR) kp.k += BK;
+        else kp.advance(s);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_VECS; ++j)
+            *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * j) * LDK + c4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_VECS; ++j)
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * j) * LDK + c4) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    const int KT = (s.Ktot + BK - 1) / BK;
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_stage();                // global loads in flight during the MFMAs
+        mfma_stage<TM, TN>(As + buf * BM * LDK, Bs + buf * BN * LDK, wm * TM * 32, wn * TN * 32, lane, acc);
+        if (kt + 1 < KT) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + ln;
+        const bool n_ok = n < s.Cout;
+        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int m = mb + (i & 3) + 8 * (i >> 2);
+                float v = acc[tm][tn][i];
+                if (m < M && n_ok) {
+                    ssum += v;
+                    ssq += v * v;
+                    p.y[(size_t)m * s.Cout + n] = apply_act(v + bv, p.act);
+                }
+            }
+        }
+        if (p.stats) {
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (lh == 0 && n_ok) {
+                atomicAdd(p.stats + n, ssum);
+                atomicAdd(p.stats + s.Cout + n, ssq);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+void launch_cfg(const FwdParams& p, hipStream_t st) {
+    int M = p.s.B * p.s.Ho * p.s.Wo;
+    dim3 grid((M + BM - 1) / BM, (p.s.Cout + BN - 1) / BN);
+    size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    auto kern = conv_fwd_kernel<BM, BN, WM, WN, MODE, FOLD>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+}
+
+template <int MODE, bool FOLD>
+void launch_mode(const FwdParams& p, hipStream_t st) {
+    const ConvShape& s = p.s;
+    const int M = s.B * s.Ho * s.Wo;
+    if (s.Cout > 64) {
+        // few output pixels (layer3/4, pose decoder): halve the M tile so the grid still covers the 256 CUs
+        if (((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st);
+        else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st);
+    } else if (s.Cout > 32) {
+        launch_cfg<128, 64, 2, 2, MODE, FOLD>(p, st);
+    } else {
+        launch_cfg<128, 32, 4, 1, MODE, FOLD>(p, st);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d,
+                   const dvs_conv_fusion* f, void* stream) {
+    DVS_REQUIRE(x && w && y && d, "dvs_conv2d_fwd: null pointer");
+    DVS_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
+                    d->stride > 0 && d->pad >= 0,
+                "dvs_conv2d_fwd: bad descriptor");
+    FwdParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    ConvShape& s = p.s;
+    s.B = d->B; s.H = d->H; s.W = d->W; s.Cin = d->Cin; s.Cout = d->Cout;
+    s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
+    s.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    s.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    DVS_REQUIRE(s.Ho > 0 && s.Wo > 0, "dvs_conv2d_fwd: empty output");
+    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad < d->H && d->pad < d->W), "dvs_conv2d_fwd: reflect pad too large");
+    int planar = 0;
+    if (f) {
+        p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
+        p.t.in_relu = f->in_relu; planar = f->nchw_planar;
+        p.act = f->act; p.stats = f->stats;
+        DVS_REQUIRE(!(f->x2) || (f->C1 > 0 && f->C1 < d->Cin && (f->C1 % BK) == 0 && (d->H & 1) == 0 && (d->W & 1) == 0),
+                    "dvs_conv2d_fwd: upsample+concat needs C1 %% 32 == 0 and even H, W");
+        DVS_REQUIRE(!(f->x2 && planar), "dvs_conv2d_fwd: planar input cannot be concatenated");
+        DVS_REQUIRE((f->in_scale == nullptr) == (f->in_shift == nullptr), "dvs_conv2d_fwd: in_scale/in_shift come together");
+    }
+    if (planar) {
+        DVS_REQUIRE(d->kw <= 8 && d->pad_mode == PAD_ZERO, "dvs_conv2d_fwd: planar input supports kw <= 8, zero padding");
+        s.Ktot = d->Cin * d->kh * 8;      // weights packed [Cout][Cin][kh][8]
+    } else {
+        DVS_REQUIRE((d->Cin & 3) == 0, "dvs_conv2d_fwd: NHWC input needs Cin %% 4 == 0 (got %d)", d->Cin);
+        s.Ktot = d->kh * d->kw * d->Cin;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool fold = p.t.in_scale != nullptr;
+    if (planar) {
+        if (fold) launch_mode<IN_PLANAR, true>(p, st);
+        else launch_mode<IN_PLANAR, false>(p, st);
+    } else if (p.t.x2) {
+        if (fold) launch_mode<IN_UPCAT, true>(p, st);
+        else launch_mode<IN_UPCAT, false>(p, st);
+    } else {
+        if (fold) launch_mode<IN_NHWC, true>(p, st);
+        else launch_mode<IN_NHWC, false>(p, st);
+    }
+    return dvs::check_launch("dvs_conv2d_fwd");
+}
+
+}  // extern "C"

@@ -67,6 +67,42 @@ int dvs_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1-a3  convolutions of ResnetEncoder / DepthNet decoder / PoseNet decoder as implicit GEMMs on the
+ *        fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ *        replaces nn.Conv2d inside torchvision BasicBlock (model/resnet_encoder.py:83-111),
+ *        Conv3x3 / ConvBlock (model/layers.py:106-136), the decoder's upsample + concat
+ *        (model/depthnet.py:79-88, model/layers.py:196-199) and PoseNet's head
+ *        (model/posenet_single.py:174-202).
+ *   Layout: activations NHWC (torch channels_last of the reference's NCHW tensors), weights
+ *   [Cout][kh][kw][Cin] (torch channels_last of the reference's [Cout,Cin,kh,kw] parameter).
+ *   Output size: Ho = (H + 2 pad - kh)/stride + 1 (same for W).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, H, W, Cin, Cout;
+    int kh, kw, stride;
+    int pad;        /* implicit padding on every side */
+    int pad_mode;   /* 0 = zeros (nn.Conv2d padding), 1 = nn.ReflectionPad2d(pad) in front of the conv */
+} dvs_conv_desc;
+
+typedef struct {
+    /* input-side fusion (applied while the im2col slice is gathered) */
+    const float* x2;        /* non-NULL: input = concat(upsample_nearest2x(x [B,H/2,W/2,C1]), x2 [B,H,W,Cin-C1]) */
+    int C1;
+    const float* in_scale;  /* non-NULL: x <- x * in_scale[c] + in_shift[c] (folded BatchNorm / input normalisation) */
+    const float* in_shift;
+    int in_relu;            /* then ReLU */
+    int nchw_planar;        /* x is a planar [B,Cin,H,W] image (encoder conv1); any Cin */
+    /* output-side fusion */
+    int act;                /* 0 none, 1 ReLU, 2 ELU(alpha=1), 3 sigmoid */
+    float* stats;           /* non-NULL: [2][Cout], += per-channel sum and sum of squares of the raw
+                               (pre-bias, pre-activation) output: BatchNorm batch statistics */
+} dvs_conv_fusion;
+
+/* y [B,Ho,Wo,Cout] = act(conv(x, w) + bias); `f` may be NULL (no fusion). */
+int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d,
+                   const dvs_conv_fusion* f, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion
  *     replaces transformation_from_parameters / rot_from_axisangle / get_translation_matrix
  *     (vo/learner_func.py:29-104 == model/layers.py:28-103).
