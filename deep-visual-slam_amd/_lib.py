@@ -53,6 +53,9 @@ class ConvFusion(C.Structure):
 
 _SIGNATURES = {
     "dvs_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp]),
+    "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp]),
+    "dvs_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp, C.c_int, _vp]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),

@@ -2,7 +2,11 @@
 
 Tensors keep the reference's logical NCHW shapes but live in torch's channels_last memory format
 (NHWC in HBM), weights likewise ([Cout][kh][kw][Cin] in HBM); nothing is transposed on the way in or
-out of a kernel.
+out of a kernel.  One call covers what the reference spells as several modules:
+
+    ReflectionPad2d(1) -> Conv2d -> ELU                          (model/layers.py:106-136)
+    upsample(x) ; cat([x, skip], 1) -> ConvBlock                 (model/depthnet.py:79-88)
+    (x - 0.45) / 0.225 -> conv1                                  (model/resnet_encoder.py:102-103)
 """
 import ctypes as C
 
@@ -16,14 +20,13 @@ CL = torch.channels_last
 
 
 def _nhwc(t):
-    """Contiguous-NHWC view requirement (a [B,1,H,W] or [B,C,1,1] tensor is both NCHW and NHWC)."""
+    """Contiguous-NHWC requirement (a [B,1,H,W] or [B,C,1,1] tensor is both NCHW and NHWC)."""
     if t.dtype != torch.float32:
         raise _lib.DvsError("fp32 tensors only (got %s)" % t.dtype)
     return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
 
 
-def _desc(x_shape, w_shape, stride, pad, reflect):
-    B, Cin, H, W = x_shape
+def _desc(B, Cin, H, W, w_shape, stride, pad, reflect):
     Cout, _, kh, kw = w_shape
     d = ConvDesc()
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, Cout
@@ -35,58 +38,159 @@ def out_hw(H, W, kh, kw, stride, pad):
     return (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
 
 
-def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=None, x2=None, in_scale=None,
-                   in_shift=None, in_relu=False, nchw_planar=False, stats=None):
-    """Raw forward launch (no autograd).  x: logical [B,Cin,H,W] (NHWC memory, or planar NCHW when
-    nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1)."""
-    if not (x.is_cuda and weight.is_cuda):
-        raise _lib.DvsError("conv2d: GPU tensors only; this package has no CPU path")
+def _geometry(x, w_shape, x2, nchw_planar):
+    """(x, x2, B, Cin, H, W) with layouts normalised for the kernels."""
     if nchw_planar:
-        # encoder conv1: planar image in, weights packed [Cout][Cin][kh][8] (kw padded to 8 with zeros)
-        if not x.is_contiguous():
-            x = x.contiguous()
+        x = x if x.is_contiguous() else x.contiguous()
         B, Cin, H, W = x.shape
-        w = torch.nn.functional.pad(weight.contiguous(), (0, 8 - weight.shape[3]))
     else:
-        w = _nhwc(weight)
         x = _nhwc(x)
-        B, C1, H, W = x.shape
-        Cin = C1
+        B, Cin, H, W = x.shape
         if x2 is not None:
             x2 = _nhwc(x2)
             H, W = x2.shape[2], x2.shape[3]
             if (x.shape[2] * 2, x.shape[3] * 2) != (H, W):
                 raise _lib.DvsError("upsample+concat fusion: skip tensor must be exactly 2x the coarse one")
-            Cin = C1 + x2.shape[1]
-    if weight.shape[1] != Cin:
-        raise _lib.DvsError("weight expects %d input channels, got %d" % (weight.shape[1], Cin))
-    d = _desc((B, Cin, H, W), weight.shape, stride, pad, reflect)
-    Ho, Wo = out_hw(H, W, d.kh, d.kw, stride, pad)
-    y = torch.empty((B, d.Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+            Cin = x.shape[1] + x2.shape[1]
+    if w_shape[1] != Cin:
+        raise _lib.DvsError("weight expects %d input channels, got %d" % (w_shape[1], Cin))
+    return x, x2, B, Cin, H, W
+
+
+def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None):
     f = ConvFusion()
     if x2 is not None:
-        f.x2, f.C1 = ptr_nhwc(x2), x.shape[1]
+        f.x2, f.C1 = x2.data_ptr(), x.shape[1]
     if in_scale is not None:
         f.in_scale, f.in_shift, f.in_relu = ptr(in_scale), ptr(in_shift), int(bool(in_relu))
     f.nchw_planar = int(bool(nchw_planar))
     f.act = ACT[act]
     if stats is not None:
         f.stats = ptr(stats)
+    return f
+
+
+def _pack_planar_weight(weight):
+    """Encoder conv1: [Cout][Cin][kh][8] with kw zero-padded to 8 (K order (ci,ky,kx))."""
+    return torch.nn.functional.pad(weight.contiguous(), (0, 8 - weight.shape[3]))
+
+
+def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=None, x2=None, in_scale=None,
+                   in_shift=None, in_relu=False, nchw_planar=False, stats=None):
+    """Raw forward launch (no autograd).  x: logical [B,Cin,H,W] (NHWC memory, or planar NCHW when
+    nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1)."""
+    if not (x.is_cuda and weight.is_cuda):
+        raise _lib.DvsError("conv2d: GPU tensors only; this package has no CPU path")
+    x, x2, B, Cin, H, W = _geometry(x, tuple(weight.shape), x2, nchw_planar)
+    w = _pack_planar_weight(weight) if nchw_planar else _nhwc(weight)
+    d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
+    Ho, Wo = out_hw(H, W, d.kh, d.kw, stride, pad)
+    y = torch.empty((B, d.Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats)
     check(_lib.lib().dvs_conv2d_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), C.byref(f),
                                     _lib.stream()), "dvs_conv2d_fwd")
     return y
 
 
-def ptr_nhwc(t):
-    if not t.is_cuda:
-        raise _lib.DvsError("GPU tensors only")
-    return t.data_ptr()
+def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None):
+    """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect)."""
+    l = _lib.lib()
+    dy = _nhwc(dy)
+    w = _nhwc(weight)
+    Cout, Cin, kh, kw = weight.shape
+    B, _, H, W = x_shape
+    wt = torch.empty(Cin * kh * kw * Cout, device=dy.device, dtype=torch.float32)
+    check(l.dvs_conv2d_pack_wt(w.data_ptr(), wt.data_ptr(), Cout, Cin, kh, kw, _lib.stream()), "dvs_conv2d_pack_wt")
+    d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
+    dx = torch.empty((B, Cin, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
+    dact = ACT[act]
+    yo = _nhwc(y_out).data_ptr() if dact else None
+    check(l.dvs_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact, _lib.stream()),
+          "dvs_conv2d_dgrad")
+    return dx
 
 
-def supported(x, weight, stride, padding, reflect_pad):
-    """True when a hand-written kernel exists for this problem."""
-    return False
+def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=None, act=None, x2=None, in_scale=None,
+                 in_shift=None, in_relu=False, nchw_planar=False):
+    """(dW with the weight's logical shape, dbias or None)."""
+    l = _lib.lib()
+    dy = _nhwc(dy)
+    Cout, _, kh, kw = weight_shape
+    x, x2, B, Cin, H, W = _geometry(x, tuple(weight_shape), x2, nchw_planar)
+    d = _desc(B, Cin, H, W, weight_shape, stride, pad, reflect)
+    if nchw_planar:
+        dw = torch.zeros((Cout, Cin, kh, 8), device=dy.device, dtype=torch.float32)
+    else:
+        dw = torch.zeros(tuple(weight_shape), device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
+    db = torch.zeros(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar)
+    dact = ACT[act]
+    yo = _nhwc(y_out).data_ptr() if dact else None
+    check(l.dvs_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ptr(db), C.byref(d), C.byref(f), yo, dact,
+                             _lib.stream()), "dvs_conv2d_wgrad")
+    if nchw_planar:
+        dw = dw[..., :kw]
+    return dw, db
 
 
-def conv2d(x, weight, bias, stride, padding, reflect_pad):
-    raise NotImplementedError
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(pad(x [, upsample+concat x2]), w) + b) with the hand-written forward / data-gradient /
+    weight-gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, x2, opts):
+        stride, pad, reflect, act, planar, scale, shift = opts
+        y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
+                           nchw_planar=planar)
+        ctx.opts = opts
+        ctx.x_shape = tuple(x.shape)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, x2, y if ACT[act] else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, x2, y = ctx.saved_tensors
+        stride, pad, reflect, act, planar, scale, shift = ctx.opts
+        dx = dx2 = dw = db = None
+        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[3])
+        if need_x:
+            if planar:
+                raise _lib.DvsError("the planar image input of conv1 has no gradient path")
+            B = ctx.x_shape[0]
+            if x2 is None:
+                dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
+            else:
+                C1, H, W = ctx.x_shape[1], x2.shape[2], x2.shape[3]
+                dcat = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act)
+                # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split
+                dx = torch.nn.functional.avg_pool2d(dcat[:, :C1], 2) * 4.0
+                dx2 = dcat[:, C1:].contiguous(memory_format=CL)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
+                                  in_scale=scale, in_shift=shift, nchw_planar=planar)
+        return dx, dw, db, dx2, None
+
+
+def supported(x, weight, x2=None, planar=False):
+    """True when the hand-written kernels cover this problem (16-byte NHWC gathers need channel counts
+    that are multiples of 4; the 1- and 6-channel heads are handled elsewhere)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cout % 4:
+        return False
+    if planar:
+        return weight.shape[3] <= 8
+    if cin % 4:
+        return False
+    if x2 is not None and x.shape[1] % 32:
+        return False
+    return True
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, planar_norm=None):
+    """Differentiable fused convolution.  reflect_pad=1 means ReflectionPad2d(1) in front of a valid conv;
+    planar_norm=(scale, shift) selects the encoder-conv1 path (planar image in, normalisation fused)."""
+    planar = planar_norm is not None
+    scale, shift = planar_norm if planar else (None, None)
+    pad, reflect = (reflect_pad, True) if reflect_pad else (padding, False)
+    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift))

@@ -29,7 +29,8 @@ enum Pad { PAD_ZERO = 0, PAD_REFLECT = 1 };
 enum InMode {
     IN_NHWC = 0,     // one NHWC tensor
     IN_UPCAT = 1,    // concat(upsample_nearest2x(x [B,H/2,W/2,C1]), x2 [B,H,W,Cin-C1])  (model/depthnet.py:81-85)
-    IN_PLANAR = 2    // planar [B,Cin,H,W] image, K ordered (ci,ky,kx8): encoder conv1 (model/resnet_encoder.py:102-103)
+    IN_PLANAR = 2,   // planar [B,Cin,H,W] image, K ordered (ci,ky,kx8): encoder conv1 (model/resnet_encoder.py:102-103)
+    IN_DGRAD = 3     // data-gradient gather: the "input" is dY [B,Ho,Wo,Cout] read at ((y+pad-ky)/stride, (x+pad-kx)/stride)
 };
 
 struct ConvShape {
@@ -46,7 +47,20 @@ struct InXform {
     const float* in_scale;   // per-channel affine (folded BatchNorm, or the input normalisation) ...
     const float* in_shift;
     int in_relu;             // ... followed by ReLU
+    const float* aux;        // IN_DGRAD / wgrad: forward output Y of the conv (same layout as dY) ...
+    int dact;                // ... whose activation derivative multiplies dY: 1 ReLU (y>0), 2 ELU (y>0 ? 1 : y+1),
+                             //     3 sigmoid (y(1-y))
 };
+
+// d act(u) / du expressed through the activation's OUTPUT y = act(u)
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+    switch (act) {
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+        case ACT_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
 
 __device__ __forceinline__ int reflect_i(int i, int n) {
     i = i < 0 ? -i : i;
@@ -123,6 +137,54 @@ __device__ __forceinline__ f32x4 gather4(const float* __restrict__ x, const Conv
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+    return v;
+}
+
+// IN_DGRAD: 4 output channels [co, co+4) of dY (x (act'(Y) if t.dact)) feeding input pixel (y,x) through tap
+// (ky,kx): source (ty,tx) = ((y + pad - ky)/stride, (x + pad - kx)/stride) when divisible and in range.
+// yp = y + pad, xp = x + pad.  s.H/s.W are dY's spatial size here, s.Cin its channel count (= conv Cout).
+// PAD_REFLECT (ReflectionPad2d(1) + 3x3 valid conv): the gradient of the mirrored border rows/columns folds
+// back: input row 1 also receives what padded row 0 received (tap ky = 0 -> dY row 0), row H-2 what padded
+// row H+1 received (tap ky = 2 -> dY row H-1); same for columns.
+__device__ __forceinline__ f32x4 load_dy4(const float* __restrict__ dy, const ConvShape& s, const InXform& t, int b,
+                                          int ty, int tx, int co) {
+    size_t o = (((size_t)b * s.H + ty) * s.W + tx) * s.Cin + co;
+    f32x4 v = *reinterpret_cast<const f32x4*>(dy + o);
+    if (t.dact) {
+        f32x4 y = *reinterpret_cast<const f32x4*>(t.aux + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= act_grad_from_out(y[j], t.dact);
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x4 gather4_dgrad(const float* __restrict__ dy, const ConvShape& s, const InXform& t,
+                                               int b, int yp, int xp, int ky, int kx, int co, bool ok) {
+    int ty = yp - ky, tx = xp - kx;
+    if (s.stride == 2) {
+        ok = ok && ((ty | tx) & 1) == 0;
+        ty >>= 1;
+        tx >>= 1;
+    }
+    ok = ok && (unsigned)ty < (unsigned)s.H && (unsigned)tx < (unsigned)s.W;
+    f32x4 v = load_dy4(dy, s, t, b, clampi(ty, s.H), clampi(tx, s.W), co);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+    if (s.pad_mode == PAD_REFLECT) {
+        // (yp, xp) = (y + 1, x + 1); rows/cols are the unpadded input's = dY's size
+        int y = yp - 1, x = xp - 1;
+        int ey = (y == 1 && ky == 0) ? 0 : ((y == s.H - 2 && ky == s.kh - 1) ? s.H - 1 : -1);
+        int ex = (x == 1 && kx == 0) ? 0 : ((x == s.W - 2 && kx == s.kw - 1) ? s.W - 1 : -1);
+        bool in_y = (unsigned)ty < (unsigned)s.H, in_x = (unsigned)tx < (unsigned)s.W;
+        if (ey >= 0 || ex >= 0) {      // border pixels only (rare, divergent)
+            f32x4 e = {0.f, 0.f, 0.f, 0.f};
+            if (ey >= 0 && in_x) e += load_dy4(dy, s, t, b, ey, tx, co);
+            if (ex >= 0 && in_y) e += load_dy4(dy, s, t, b, ty, ex, co);
+            if (ey >= 0 && ex >= 0) e += load_dy4(dy, s, t, b, ey, ex, co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += e[j];
+        }
+    }
     return v;
 }
 

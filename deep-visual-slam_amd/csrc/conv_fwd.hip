@@ -55,8 +55,13 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
         int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
         int oy = rem / s.Wo, ox = rem - oy * s.Wo;
         a_b[j] = b;
-        a_iy[j] = oy * s.stride - s.pad;
-        a_ix[j] = ox * s.stride - s.pad;
+        if (MODE == IN_DGRAD) {      // rows are input pixels; the gather subtracts the tap
+            a_iy[j] = oy + s.pad;
+            a_ix[j] = ox + s.pad;
+        } else {
+            a_iy[j] = oy * s.stride - s.pad;
+            a_ix[j] = ox * s.stride - s.pad;
+        }
     }
     // weight rows
     const float* b_ptr[B_VECS];
@@ -78,6 +83,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
         for (int j = 0; j < A_VECS; ++j) {
             if (MODE == IN_PLANAR)
                 ra[j] = gather4_planar<FOLD>(p.x, s, p.t, a_b[j], a_iy[j], a_ix[j], kc, a_ok[j] && k_ok);
+            else if (MODE == IN_DGRAD)
+                ra[j] = gather4_dgrad(p.x, s, p.t, a_b[j], a_iy[j], a_ix[j], kp.ky, kp.kx, kp.ci, a_ok[j] && k_ok);
             else
                 ra[j] = gather4<MODE, FOLD>(p.x, s, p.t, a_b[j], a_iy[j] + kp.ky, a_ix[j] + kp.kx, kp.ci,
                                             a_ok[j] && k_ok);
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
-void launch_cfg(const FwdParams& p, hipStream_t st) {
+void launch_cfg(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
     dim3 grid((M + BM - 1) / BM, (p.s.Cout + BN - 1) / BN);
     size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
@@ -166,28 +173,78 @@ void launch_cfg(const FwdParams& p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
+    dvs::ProfScope prof(slot, st);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
 }
 
 template <int MODE, bool FOLD>
-void launch_mode(const FwdParams& p, hipStream_t st) {
+void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
     const ConvShape& s = p.s;
     const int M = s.B * s.Ho * s.Wo;
     if (s.Cout > 64) {
         // few output pixels (layer3/4, pose decoder): halve the M tile so the grid still covers the 256 CUs
-        if (((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st);
-        else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st);
+        if (((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
+        else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, slot);
     } else if (s.Cout > 32) {
-        launch_cfg<128, 64, 2, 2, MODE, FOLD>(p, st);
+        launch_cfg<128, 64, 2, 2, MODE, FOLD>(p, st, slot);
     } else {
-        launch_cfg<128, 32, 4, 1, MODE, FOLD>(p, st);
+        launch_cfg<128, 32, 4, 1, MODE, FOLD>(p, st, slot);
+    }
+}
+
+// Wt[ci][tap][co] = W[co][tap][ci]: the [N][K] operand of the data-gradient GEMM (32x32 LDS tile transpose).
+__global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout,
+                                                      int Cin, int T) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int co = co0 + ty + 8 * j, ci = ci0 + tx;
+        tile[ty + 8 * j][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * T + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ci = ci0 + ty + 8 * j, co = co0 + tx;
+        if (ci < Cin && co < Cout) wt[((size_t)ci * T + tap) * Cout + co] = tile[tx][ty + 8 * j];
     }
 }
 
 }  // namespace
 
 extern "C" {
+
+int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream) {
+    DVS_REQUIRE(w && wt && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "dvs_conv2d_pack_wt: bad argument");
+    dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, kh * kw);
+    hipLaunchKernelGGL(pack_wt_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, wt, Cout, Cin, kh * kw);
+    return dvs::check_launch("dvs_conv2d_pack_wt");
+}
+
+int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
+                     int dact, void* stream) {
+    DVS_REQUIRE(dy && wt && dx && d, "dvs_conv2d_dgrad: null pointer");
+    DVS_REQUIRE(d->stride == 1 || d->stride == 2, "dvs_conv2d_dgrad: stride %d (1 or 2 supported)", d->stride);
+    DVS_REQUIRE((d->Cout & 3) == 0 && (d->Cin & 3) == 0, "dvs_conv2d_dgrad: channel counts must be multiples of 4");
+    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 4 && d->W >= 4),
+                "dvs_conv2d_dgrad: reflect mode is ReflectionPad2d(1) + 3x3 stride 1 only");
+    DVS_REQUIRE(!dact || y_out, "dvs_conv2d_dgrad: activation gradient needs the forward output");
+    FwdParams p{};
+    p.x = dy; p.w = wt; p.y = dx;
+    ConvShape& s = p.s;
+    int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    s.B = d->B;
+    s.Ho = d->H; s.Wo = d->W; s.Cout = d->Cin;        // GEMM rows = input pixels, N = input channels
+    s.H = Ho; s.W = Wo; s.Cin = d->Cout;              // gathered tensor = dY
+    s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
+    s.Ktot = d->kh * d->kw * d->Cout;
+    p.t.aux = y_out;
+    p.t.dact = dact;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    launch_mode<IN_DGRAD, false>(p, st, dvs::SLOT_CONV_DGRAD);
+    return dvs::check_launch("dvs_conv2d_dgrad");
+}
 
 int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d,
                    const dvs_conv_fusion* f, void* stream) {
@@ -224,14 +281,14 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
     if (planar) {
-        if (fold) launch_mode<IN_PLANAR, true>(p, st);
-        else launch_mode<IN_PLANAR, false>(p, st);
+        if (fold) launch_mode<IN_PLANAR, true>(p, st, dvs::SLOT_CONV_FWD);
+        else launch_mode<IN_PLANAR, false>(p, st, dvs::SLOT_CONV_FWD);
     } else if (p.t.x2) {
-        if (fold) launch_mode<IN_UPCAT, true>(p, st);
-        else launch_mode<IN_UPCAT, false>(p, st);
+        if (fold) launch_mode<IN_UPCAT, true>(p, st, dvs::SLOT_CONV_FWD);
+        else launch_mode<IN_UPCAT, false>(p, st, dvs::SLOT_CONV_FWD);
     } else {
-        if (fold) launch_mode<IN_NHWC, true>(p, st);
-        else launch_mode<IN_NHWC, false>(p, st);
+        if (fold) launch_mode<IN_NHWC, true>(p, st, dvs::SLOT_CONV_FWD);
+        else launch_mode<IN_NHWC, false>(p, st, dvs::SLOT_CONV_FWD);
     }
     return dvs::check_launch("dvs_conv2d_fwd");
 }

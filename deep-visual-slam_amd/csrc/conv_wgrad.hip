@@ -1,0 +1,234 @@
+// a1-a3 backward: weight gradient of the convolutions as a split-K implicit GEMM on the fp32 matrix cores.
+//
+//   dW[co][k] = sum_m dY[m][co] * A[m][k],   m = (b,oy,ox) over all output pixels, k = (kh,kw,ci)
+//
+// The reduction dimension is the pixel index: a workgroup owns a BM(co) x BN(k) tile of dW and a slice of
+// the pixels (blockIdx.z), stages 32 pixels per step -- the dY rows (optionally multiplied by the
+// activation derivative act'(Y)) and the matching im2col rows, gathered exactly as in the forward kernel
+// (padding, upsample+concat, BatchNorm fold) -- into LDS as [pixel][channel] and feeds
+// v_mfma_f32_32x32x2_f32 with one ds_read_b32 per operand (lanes run along the contiguous channel
+// dimension: conflict-free).  Partial tiles are combined with fp32 global atomics (128-B segments), the
+// bias gradient (column sums of dY) rides along in the k-tile-0 workgroups.
+//
+// Replaces the weight/bias gradient of nn.Conv2d (autograd of the modules cited in conv_fwd.hip).
+#include "conv_common.h"
+
+namespace {
+using namespace dvsconv;
+
+constexpr int BP = 32;   // pixels per stage
+
+struct WgradParams {
+    const float* x;      // forward input (gather source)
+    const float* dy;     // [B,Ho,Wo,Cout]
+    float* dw;           // [Cout][Ktot], accumulated with atomics (caller zero-fills)
+    float* dbias;        // [Cout] or NULL
+    ConvShape s;
+    InXform t;           // forward input transform + (aux = Y, dact) for the dY side
+    int m_per_split;     // pixels per blockIdx.z, multiple of BP
+};
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+__global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int D_VECS = BM / 32, X_VECS = BN / 32;       // 16-byte vectors per thread per stage
+    constexpr int DV = BM / 4, XV = BN / 4;                 // vectors per pixel row
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+    float* sBias = &Ds[0][0][0];    // reused after the pixel loop (the loop ends on a barrier)
+
+    const ConvShape& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = s.B * s.Ho * s.Wo;
+    const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
+    const int m_begin = blockIdx.z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
+    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0;
+
+    // dY side: my channel vector and pixel rows
+    const int d_c = (tid % DV) * 4, d_p0 = tid / DV;        // rows d_p0 + (NT/DV) * j
+    const int co = co0 + d_c;
+    const bool co_ok = co < s.Cout;                          // Cout % 4 == 0: whole vector in or out
+    // X side: my k vector (fixed for the whole kernel) and pixel rows
+    const int x_c = (tid % XV) * 4, x_p0 = tid / XV;
+    const int k = k0 + x_c;
+    const bool k_ok = k < s.Ktot;
+    int ky = 0, kx = 0, ci = 0;
+    if (MODE != IN_PLANAR) {
+        int kc = min(k, s.Ktot - 4);
+        int tap = kc / s.Cin;
+        ci = kc - tap * s.Cin;
+        ky = tap / s.kw;
+        kx = tap - ky * s.kw;
+    }
+
+    f32x4 rd[D_VECS], rx[X_VECS], bsum = {0.f, 0.f, 0.f, 0.f};
+    auto load_stage = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < D_VECS; ++j) {
+            int m = mb + d_p0 + (NT / DV) * j;
+            bool ok = m < m_end && co_ok;
+            size_t o = (size_t)min(m, M - 1) * s.Cout + min(co, s.Cout - 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + o);
+            if (p.t.dact) {
+                f32x4 y = *reinterpret_cast<const f32x4*>(p.t.aux + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(y[e], p.t.dact);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            rd[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < X_VECS; ++j) {
+            int m = mb + x_p0 + (NT / XV) * j;
+            bool ok = m < m_end && k_ok;
+            m = min(m, M - 1);
+            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+            int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+            int iy = oy * s.stride - s.pad, ix = ox * s.stride - s.pad;
+            if (MODE == IN_PLANAR) rx[j] = gather4_planar<FOLD>(p.x, s, p.t, b, iy, ix, min(k, s.Ktot - 4), ok);
+            else rx[j] = gather4<MODE, FOLD>(p.x, s, p.t, b, iy + ky, ix + kx, ci, ok);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < D_VECS; ++j) {
+            *reinterpret_cast<f32x4*>(&Ds[buf][d_p0 + (NT / DV) * j][d_c]) = rd[j];
+            bsum += rd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < X_VECS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][x_p0 + (NT / XV) * j][x_c]) = rx[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    const int a_col = wm * TM * 32 + r, b_col = wn * TN * 32 + r;
+    if (m_begin < m_end) {
+        load_stage(m_begin);
+        store_stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int mb = m_begin; mb < m_end; mb += BP) {
+        const bool more = mb + BP < m_end;
+        if (more) load_stage(mb + BP);
+#pragma unroll
+        for (int t = 0; t < BP / 2; ++t) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = Ds[buf][2 * t + h][a_col + m * 32];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = Xs[buf][2 * t + h][b_col + n * 32];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: dW[co][k] += acc.  C/D map: column (k) = lane & 31, row (co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int kk = k0 + (wn * TN + tn) * 32 + r;
+        if (kk >= s.Ktot) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int c = cb + (i & 3) + 8 * (i >> 2);
+                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
+            }
+        }
+    }
+    if (do_bias) {
+        if (tid < BM) sBias[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&sBias[d_c + e], bsum[e]);
+        __syncthreads();
+        if (tid < BM && co0 + tid < s.Cout) atomicAdd(p.dbias + co0 + tid, sBias[tid]);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+void launch_cfg(WgradParams p, hipStream_t st) {
+    const int M = p.s.B * p.s.Ho * p.s.Wo;
+    const int tiles = ((p.s.Cout + BM - 1) / BM) * ((p.s.Ktot + BN - 1) / BN);
+    int splits = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in flight
+    splits = max(1, min(splits, (M + 255) / 256));           // at least 8 stages per workgroup
+    int mps = ((M + splits - 1) / splits + BP - 1) / BP * BP;
+    splits = (M + mps - 1) / mps;
+    p.m_per_split = mps;
+    dim3 grid((p.s.Cout + BM - 1) / BM, (p.s.Ktot + BN - 1) / BN, splits);
+    dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD>), grid, dim3(NT), 0, st, p);
+}
+
+template <int MODE, bool FOLD>
+void launch_mode(const WgradParams& p, hipStream_t st) {
+    if (p.s.Cout > 64) launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st);
+    else if (p.s.Cout > 32) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st);
+    else launch_cfg<32, 128, 1, 4, MODE, FOLD>(p, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
+                     const dvs_conv_fusion* f, const float* y_out, int dact, void* stream) {
+    DVS_REQUIRE(x && dy && dw && d, "dvs_conv2d_wgrad: null pointer");
+    DVS_REQUIRE((d->Cout & 3) == 0, "dvs_conv2d_wgrad: Cout must be a multiple of 4 (got %d)", d->Cout);
+    DVS_REQUIRE(!dact || y_out, "dvs_conv2d_wgrad: activation gradient needs the forward output");
+    WgradParams p{};
+    p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
+    ConvShape& s = p.s;
+    s.B = d->B; s.H = d->H; s.W = d->W; s.Cin = d->Cin; s.Cout = d->Cout;
+    s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
+    s.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    s.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    int planar = 0;
+    if (f) {
+        p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
+        p.t.in_relu = f->in_relu; planar = f->nchw_planar;
+    }
+    p.t.aux = y_out;
+    p.t.dact = dact;
+    if (planar) {
+        DVS_REQUIRE(d->kw <= 8 && d->pad_mode == PAD_ZERO, "dvs_conv2d_wgrad: planar input supports kw <= 8, zero padding");
+        s.Ktot = d->Cin * d->kh * 8;
+    } else {
+        DVS_REQUIRE((d->Cin & 3) == 0, "dvs_conv2d_wgrad: NHWC input needs Cin %% 4 == 0 (got %d)", d->Cin);
+        s.Ktot = d->kh * d->kw * d->Cin;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool fold = p.t.in_scale != nullptr;
+    if (planar) {
+        if (fold) launch_mode<IN_PLANAR, true>(p, st);
+        else launch_mode<IN_PLANAR, false>(p, st);
+    } else if (p.t.x2) {
+        if (fold) launch_mode<IN_UPCAT, true>(p, st);
+        else launch_mode<IN_UPCAT, false>(p, st);
+    } else {
+        if (fold) launch_mode<IN_NHWC, true>(p, st);
+        else launch_mode<IN_NHWC, false>(p, st);
+    }
+    return dvs::check_launch("dvs_conv2d_wgrad");
+}
+
+}  // extern "C"

@@ -102,6 +102,24 @@ typedef struct {
 int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d,
                    const dvs_conv_fusion* f, void* stream);
 
+/* Backward of dvs_conv2d_fwd.
+ *   dvs_conv2d_pack_wt: wt[ci][kh][kw][co] = w[co][kh][kw][ci], the [N][K] operand of the data gradient.
+ *   dvs_conv2d_dgrad:   dx [B,H,W,Cin] = conv_transpose(dy * act'(y_out), w).  `d` describes the FORWARD
+ *                       conv; stride 1 or 2; pad_mode 1 only for ReflectionPad2d(1) + 3x3 (the reflection's
+ *                       gradient fold is done in the gather).  y_out/dact: forward output and its
+ *                       activation code (0 = dy is already the pre-activation gradient).  For an
+ *                       upsample+concat forward, dx is the gradient of the concatenated [B,H,W,Cin] input.
+ *   dvs_conv2d_wgrad:   dw [Cout][Ktot] += sum_pixels (dy * act'(y_out)) x im2col(x), dbias [Cout] += column
+ *                       sums (NULL = skip); both are accumulated with atomics, the caller zero-fills.  `f`
+ *                       carries the forward's input-side fusion (x2/C1, in_scale/in_shift/in_relu,
+ *                       nchw_planar; act/stats ignored).  With nchw_planar dw is packed [Cout][Cin][kh][8].
+ *   Channel counts must be multiples of 4 (NHWC 16-byte gathers). */
+int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
+int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
+                     int dact, void* stream);
+int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
+                     const dvs_conv_fusion* f, const float* y_out, int dact, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion
  *     replaces transformation_from_parameters / rot_from_axisangle / get_translation_matrix

@@ -1,0 +1,117 @@
+"""GPU parity of the hand-written implicit-GEMM convolution (forward, data gradient, weight/bias
+gradient, fused pad / upsample+concat / activation / input normalisation) against torch's own fp32
+composition of the reference modules (F.pad reflect, F.interpolate nearest, torch.cat, F.conv2d, F.elu).
+
+Tolerance: exact-fp32 MFMA vs MIOpen fp32 -- both sum K <= 4608 products in a different order:
+relative 2e-5 of the tensor's max on values, 1e-4 on gradients (sums over up to 1e5 pixels).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def ref_act(y, act):
+    return {None: lambda v: v, "elu": F.elu, "relu": F.relu, "sigmoid": torch.sigmoid}[act](y)
+
+
+CASES = [
+    # name, B, Cin, Cout, k, stride, pad, reflect, H, W, act, bias
+    ("3x3_s1", 2, 64, 64, 3, 1, 1, False, 24, 40, None, False),
+    ("3x3_s2", 2, 64, 128, 3, 2, 1, False, 24, 40, None, False),
+    ("1x1_s2", 2, 64, 128, 1, 2, 0, False, 24, 40, None, False),
+    ("3x3_deep", 3, 256, 256, 3, 1, 1, False, 9, 13, None, False),
+    ("refl_elu", 2, 32, 16, 3, 1, 1, True, 20, 36, "elu", True),
+    ("refl_elu_c16", 1, 16, 16, 3, 1, 1, True, 33, 47, "elu", True),
+    ("relu_bias_1x1", 2, 512, 256, 1, 1, 0, False, 7, 9, "relu", True),
+    ("relu_bias_3x3", 2, 256, 256, 3, 1, 1, False, 7, 9, "relu", True),
+    ("odd_tail", 1, 20, 36, 3, 1, 1, False, 11, 17, None, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_fwd_bwd(gpu_device, case):
+    from deep_visual_slam_amd import conv as DC
+    name, B, ci, co, k, s, p, refl, H, W, act, has_b = case
+    torch.manual_seed(0)
+    x = torch.randn(B, ci, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, ci, k, k, device=gpu_device) * (2.0 / (ci * k * k)) ** 0.5).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(co, device=gpu_device) * 0.1).requires_grad_(True) if has_b else None
+    xx = F.pad(x, (p,) * 4, mode="reflect") if refl else x
+    y_ref = ref_act(F.conv2d(xx, w, b, s, 0 if refl else p), act)
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [x, w] + ([b] if has_b else []), cot)
+    y = DC.conv2d(x, w, b, s, p, 1 if refl else 0, act)
+    assert y.shape == y_ref.shape and y.is_contiguous(memory_format=CL)
+    assert relmax(y, y_ref) < 2e-5
+    g = torch.autograd.grad(y, [x, w] + ([b] if has_b else []), cot)
+    for a, r, nm in zip(g, g_ref, ("dx", "dw", "db")):
+        assert a.shape == r.shape, nm
+        assert relmax(a, r) < 1e-4, (nm, relmax(a, r))
+
+
+@pytest.mark.parametrize("c1,c2,co,H,W", [(32, 64, 32, 24, 40), (256, 256, 128, 10, 14)])
+def test_upsample_concat_conv(gpu_device, c1, c2, co, H, W):
+    """upsample(x) ; cat([x, skip]) ; ConvBlock (model/depthnet.py:79-88) as one call."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(1)
+    B = 2
+    xa = torch.randn(B, c1, H // 2, W // 2, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    xb = torch.randn(B, c2, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, c1 + c2, 3, 3, device=gpu_device) * 0.03).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(co, device=gpu_device) * 0.1).requires_grad_(True)
+    cat = torch.cat([F.interpolate(xa, scale_factor=2, mode="nearest"), xb], 1)
+    y_ref = F.elu(F.conv2d(F.pad(cat, (1,) * 4, mode="reflect"), w, b))
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [xa, xb, w, b], cot)
+    y = DC.conv2d(xa, w, b, 1, 0, 1, "elu", x2=xb)
+    assert relmax(y, y_ref) < 2e-5
+    g = torch.autograd.grad(y, [xa, xb, w, b], cot)
+    for a, r, nm in zip(g, g_ref, ("dxa", "dxb", "dw", "db")):
+        assert a.shape == r.shape and relmax(a, r) < 1e-4, (nm, relmax(a, r))
+
+
+@pytest.mark.parametrize("cin", [3, 6])
+def test_conv1_planar_with_input_normalisation(gpu_device, cin):
+    """(x - 0.45) / 0.225 -> conv 7x7 stride 2 pad 3 from the planar NCHW image (resnet_encoder.py:102-103)."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(2)
+    x = torch.rand(2, cin, 38, 50, device=gpu_device)
+    w = (torch.randn(64, cin, 7, 7, device=gpu_device) * 0.05).requires_grad_(True)
+    y_ref = F.conv2d((x - 0.45) / 0.225, w, None, 2, 3)
+    cot = torch.randn_like(y_ref)
+    (gw_ref,) = torch.autograd.grad(y_ref, [w], cot)
+    sc = torch.full((cin,), 1 / 0.225, device=gpu_device)
+    sh = torch.full((cin,), -0.45 / 0.225, device=gpu_device)
+    y = DC.conv2d(x, w, None, 2, 3, 0, None, planar_norm=(sc, sh))
+    assert relmax(y, y_ref) < 2e-5
+    (gw,) = torch.autograd.grad(y, [w], cot)
+    assert gw.shape == gw_ref.shape and relmax(gw, gw_ref) < 1e-4
+
+
+def test_bn_fold_and_stats_epilogue(gpu_device):
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 20, 24, device=gpu_device).contiguous(memory_format=CL)
+    w = (torch.randn(64, 64, 3, 3, device=gpu_device) * 0.05).contiguous(memory_format=CL)
+    sc, sh = torch.rand(64, device=gpu_device) + 0.5, torch.randn(64, device=gpu_device) * 0.2
+    stats = torch.zeros(2, 64, device=gpu_device)
+    y = DC.conv2d_forward(x, w, None, 1, 1, False, None, in_scale=sc, in_shift=sh, in_relu=True, stats=stats)
+    y_ref = F.conv2d(F.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), w, None, 1, 1)
+    assert relmax(y, y_ref) < 2e-5
+    assert relmax(stats[0], y_ref.sum((0, 2, 3))) < 1e-4
+    assert relmax(stats[1], (y_ref ** 2).sum((0, 2, 3))) < 1e-4
+
+
+def test_unsupported_shapes_are_reported(gpu_device):
+    from deep_visual_slam_amd import conv as DC
+    x = torch.zeros(1, 16, 8, 8, device=gpu_device)
+    assert not DC.supported(x, torch.zeros(1, 16, 3, 3))       # 1-channel disparity head
+    assert not DC.supported(x, torch.zeros(6, 256, 1, 1))      # 6-channel pose head
+    assert DC.supported(x, torch.zeros(16, 16, 3, 3))
