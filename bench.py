@@ -173,8 +173,9 @@ def main():
 
     if rank == 0:
         # roofline of the dominant hand-written kernel inside the timed region
-        per_kernel = {k: (ms / n, n) for k, (ms, n) in prof.items()}
-        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        per_kernel = {k: (ms / n, n) for k, (ms, n, _) in prof.items()}
+        per_step = {k: ms / args.steps for k, (ms, n, _) in prof.items()}
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None      # most time inside the timed region
         roof = None
         if dom in ("chain_fwd_kernel", "chain_bwd_kernel"):
             nbytes = CHAIN_FWD_BYTES[num_scales] * batch      # fwd and bwd move the same compulsory bytes
@@ -183,6 +184,19 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": per_kernel[dom][0],
                     "algorithmic_bytes_per_launch": nbytes}
+        elif dom is not None and dom.startswith("conv_"):
+            # the conv kernels run once per layer with different shapes: achieved = sum of the launches'
+            # algorithmic flops (2*M*N*K, counted inside the library) / sum of their HIP-event durations
+            ms, n, flops = prof[dom]
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / n,
+                    "launches_per_step": n / args.steps, "algorithmic_flops_per_step": flops / args.steps}
+        all_conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
+        conv_summary = None
+        if all_conv:
+            conv_summary = {k: {"ms_per_step": v[0] / args.steps, "tflops": v[2] / (v[0] * 1e-3) / 1e12}
+                            for k, v in all_conv.items()}
         out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -191,7 +205,8 @@ def main():
                           "num_scales": num_scales, "image": "%dx%d" % (W, H),
                           "parallelism": "dp%d" % world, "conv_backend": os.environ.get("DVS_CONV_BACKEND", "hip")},
                "loss": loss_val,
-               "kernels_ms": {k: round(v[0], 4) for k, v in per_kernel.items()},
+               "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
+               "conv_kernels": conv_summary,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, num_scales)

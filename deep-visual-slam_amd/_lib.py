@@ -63,6 +63,7 @@ _SIGNATURES = {
     "dvs_profile_slots": (C.c_int, []),
     "dvs_profile_slot_name": (C.c_char_p, [C.c_int]),
     "dvs_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    "dvs_profile_work": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "dvs_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, C.c_float, C.c_int, _vp]),
     "dvs_pose_to_mat_fwd": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),

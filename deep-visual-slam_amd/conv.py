@@ -38,6 +38,9 @@ def out_hw(H, W, kh, kw, stride, pad):
     return (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
 
 
+UPSAMPLE_ONLY = "upsample-only"   # x2 marker: the logical input is upsample2x(x) with nothing concatenated
+
+
 def _geometry(x, w_shape, x2, nchw_planar):
     """(x, x2, B, Cin, H, W) with layouts normalised for the kernels."""
     if nchw_planar:
@@ -46,7 +49,9 @@ def _geometry(x, w_shape, x2, nchw_planar):
     else:
         x = _nhwc(x)
         B, Cin, H, W = x.shape
-        if x2 is not None:
+        if x2 is UPSAMPLE_ONLY:
+            H, W = 2 * H, 2 * W
+        elif x2 is not None:
             x2 = _nhwc(x2)
             H, W = x2.shape[2], x2.shape[3]
             if (x.shape[2] * 2, x.shape[3] * 2) != (H, W):
@@ -59,7 +64,9 @@ def _geometry(x, w_shape, x2, nchw_planar):
 
 def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None):
     f = ConvFusion()
-    if x2 is not None:
+    if x2 is UPSAMPLE_ONLY:
+        f.x2, f.C1 = x.data_ptr(), x.shape[1]      # C1 == Cin: the second source is never read
+    elif x2 is not None:
         f.x2, f.C1 = x2.data_ptr(), x.shape[1]
     if in_scale is not None:
         f.in_scale, f.in_shift, f.in_relu = ptr(in_scale), ptr(in_shift), int(bool(in_relu))
@@ -145,7 +152,8 @@ class _Conv2d(torch.autograd.Function):
         ctx.opts = opts
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, weight, x2, y if ACT[act] else None)
+        ctx.up_only = x2 is UPSAMPLE_ONLY
+        ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
         return y
 
     @staticmethod
@@ -153,7 +161,9 @@ class _Conv2d(torch.autograd.Function):
         x, weight, x2, y = ctx.saved_tensors
         stride, pad, reflect, act, planar, scale, shift = ctx.opts
         dx = dx2 = dw = db = None
-        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[3])
+        if ctx.up_only:
+            x2 = UPSAMPLE_ONLY
+        need_x = ctx.needs_input_grad[0] or (isinstance(x2, torch.Tensor) and ctx.needs_input_grad[3])
         if need_x:
             if planar:
                 raise _lib.DvsError("the planar image input of conv1 has no gradient path")
@@ -161,18 +171,19 @@ class _Conv2d(torch.autograd.Function):
             if x2 is None:
                 dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
             else:
-                C1, H, W = ctx.x_shape[1], x2.shape[2], x2.shape[3]
+                C1, H, W = ctx.x_shape[1], 2 * ctx.x_shape[2], 2 * ctx.x_shape[3]
                 dcat = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act)
                 # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split
                 dx = torch.nn.functional.avg_pool2d(dcat[:, :C1], 2) * 4.0
-                dx2 = dcat[:, C1:].contiguous(memory_format=CL)
+                if not ctx.up_only:
+                    dx2 = dcat[:, C1:].contiguous(memory_format=CL)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
                                   in_scale=scale, in_shift=shift, nchw_planar=planar)
         return dx, dw, db, dx2, None
 
 
-def supported(x, weight, x2=None, planar=False):
+def supported(x, weight, x2=None, planar=False, upsample=False):
     """True when the hand-written kernels cover this problem (16-byte NHWC gathers need channel counts
     that are multiples of 4; the 1- and 6-channel heads are handled elsewhere)."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -187,10 +198,14 @@ def supported(x, weight, x2=None, planar=False):
     return True
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, planar_norm=None):
+def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
+           planar_norm=None):
     """Differentiable fused convolution.  reflect_pad=1 means ReflectionPad2d(1) in front of a valid conv;
-    planar_norm=(scale, shift) selects the encoder-conv1 path (planar image in, normalisation fused)."""
+    x2 / upsample select the decoder's upsample(+concat) gather; planar_norm=(scale, shift) selects the
+    encoder-conv1 path (planar image in, normalisation fused)."""
     planar = planar_norm is not None
     scale, shift = planar_norm if planar else (None, None)
     pad, reflect = (reflect_pad, True) if reflect_pad else (padding, False)
+    if x2 is None and upsample:
+        x2 = UPSAMPLE_ONLY
     return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift))

@@ -30,6 +30,7 @@ enum ProfSlot { SLOT_CHAIN_FWD = 0, SLOT_CHAIN_BWD, SLOT_ADAM, SLOT_CONV_FWD, SL
 bool prof_enabled();
 void prof_begin(int slot, hipStream_t st, hipEvent_t* start);
 void prof_end(int slot, hipStream_t st, hipEvent_t start);
+void prof_work(int slot, double work);
 
 struct ProfScope {
     int slot;
@@ -38,6 +39,9 @@ struct ProfScope {
     bool on;
     ProfScope(int s, hipStream_t stream) : slot(s), st(stream), on(prof_enabled()) {
         if (on) prof_begin(slot, st, &start);
+    }
+    void work(double w) {
+        if (on) prof_work(slot, w);
     }
     ~ProfScope() {
         if (on) prof_end(slot, st, start);

@@ -102,10 +102,18 @@ struct KPos {
     }
 };
 
-// One 16-byte slice (4 channels at ci) of input pixel (b, iy, ix); `ok` folds row validity and k < Ktot.
-template <int MODE, bool FOLD>
-__device__ __forceinline__ f32x4 gather4(const float* __restrict__ x, const ConvShape& s, const InXform& t, int b,
-                                         int iy, int ix, int ci, bool ok) {
+// ---------------------------------------------------------------------------------------------
+// Gathers come in two halves so that a stage's global loads stay in flight across the MFMAs of the
+// previous stage: `*_raw` only issues the (unconditional, clamped-address) loads and returns the validity
+// flag; `finalize*` -- called right before the LDS store, after the MFMAs -- applies the padding zeros,
+// the folded BatchNorm / activation-derivative arithmetic.  (Selecting the zeros next to the load would put
+// an s_waitcnt vmcnt(0) in front of the MFMAs and serialise HBM latency with the matrix pipe.)
+// ---------------------------------------------------------------------------------------------
+
+// 16-byte slice (4 channels at ci) of input pixel (b, iy, ix); `ok` comes in with row validity & k < Ktot.
+template <int MODE>
+__device__ __forceinline__ f32x4 gather_raw(const float* __restrict__ x, const ConvShape& s, const InXform& t, int b,
+                                            int iy, int ix, int ci, bool& ok) {
     if (s.pad_mode == PAD_REFLECT) {
         iy = reflect_i(iy, s.H);
         ix = reflect_i(ix, s.W);
@@ -114,38 +122,101 @@ __device__ __forceinline__ f32x4 gather4(const float* __restrict__ x, const Conv
     }
     iy = clampi(iy, s.H);
     ix = clampi(ix, s.W);
-    f32x4 v;
     if (MODE == IN_UPCAT) {
         if (ci < t.C1) {     // block-uniform: C1 is a multiple of the 32-channel stage
             int h2 = s.H >> 1, w2 = s.W >> 1;
-            v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * h2 + (iy >> 1)) * w2 + (ix >> 1)) * t.C1 + ci);
-        } else {
-            int c2 = s.Cin - t.C1;
-            v = *reinterpret_cast<const f32x4*>(t.x2 + (((size_t)b * s.H + iy) * s.W + ix) * c2 + (ci - t.C1));
+            return *reinterpret_cast<const f32x4*>(x + (((size_t)b * h2 + (iy >> 1)) * w2 + (ix >> 1)) * t.C1 + ci);
         }
+        int c2 = s.Cin - t.C1;
+        return *reinterpret_cast<const f32x4*>(t.x2 + (((size_t)b * s.H + iy) * s.W + ix) * c2 + (ci - t.C1));
+    }
+    return *reinterpret_cast<const f32x4*>(x + (((size_t)b * s.H + iy) * s.W + ix) * s.Cin + ci);
+}
+
+// Per-(row, tap) part of the gather, hoisted out of the K loop: padding / reflection / clamping and the pixel's
+// element offset(s) are computed once per tap (every Cin/32 stages), a stage then only adds its channel.
+// Offsets are 32-bit element indices (the host checks numel < 2^31).
+template <int MODE>
+__device__ __forceinline__ void tap_setup(const ConvShape& s, const InXform& t, int b, int iy, int ix, bool& ok,
+                                          int& off, int& off2) {
+    if (s.pad_mode == PAD_REFLECT) {
+        iy = reflect_i(iy, s.H);
+        ix = reflect_i(ix, s.W);
     } else {
-        v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * s.H + iy) * s.W + ix) * s.Cin + ci);
+        ok = ok && (unsigned)iy < (unsigned)s.H && (unsigned)ix < (unsigned)s.W;
     }
-    if (FOLD) {
-        f32x4 sc = *reinterpret_cast<const f32x4*>(t.in_scale + ci);
-        f32x4 sh = *reinterpret_cast<const f32x4*>(t.in_shift + ci);
+    iy = clampi(iy, s.H);
+    ix = clampi(ix, s.W);
+    if (MODE == IN_UPCAT) {
+        int h2 = s.H >> 1, w2 = s.W >> 1;
+        off = ((b * h2 + (iy >> 1)) * w2 + (ix >> 1)) * t.C1;
+        off2 = ((b * s.H + iy) * s.W + ix) * (s.Cin - t.C1) - t.C1;     // + ci lands on channel ci - C1
+    } else {
+        off = ((b * s.H + iy) * s.W + ix) * s.Cin;
+        off2 = 0;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4 load_tap4(const float* __restrict__ x, const InXform& t, int off, int off2, int ci) {
+    if (MODE == IN_UPCAT && ci >= t.C1) return *reinterpret_cast<const f32x4*>(t.x2 + (off2 + ci));
+    return *reinterpret_cast<const f32x4*>(x + (off + ci));
+}
+
+// Same for the data-gradient gather: offset of dY pixel ((yp-ky)/stride, (xp-kx)/stride) and its validity.
+__device__ __forceinline__ void dgrad_tap_setup(const ConvShape& s, int b, int yp, int xp, int ky, int kx, bool& ok,
+                                                int& off) {
+    int ty = yp - ky, tx = xp - kx;
+    if (s.stride == 2) {
+        ok = ok && ((ty | tx) & 1) == 0;
+        ty >>= 1;
+        tx >>= 1;
+    }
+    ok = ok && (unsigned)ty < (unsigned)s.H && (unsigned)tx < (unsigned)s.W;
+    off = ((b * s.H + clampi(ty, s.H)) * s.W + clampi(tx, s.W)) * s.Cin;
+}
+
+// Reflection fold of the data gradient (see gather_dgrad_raw): extra terms of border pixels, already
+// multiplied by the activation derivative.
+__device__ __forceinline__ f32x4 load_dy4(const float* __restrict__ dy, const ConvShape& s, const InXform& t, int b,
+                                          int ty, int tx, int co);
+__device__ __forceinline__ f32x4 dgrad_reflect_extra(const float* __restrict__ dy, const ConvShape& s,
+                                                     const InXform& t, int b, int yp, int xp, int ky, int kx, int co,
+                                                     bool row_ok) {
+    f32x4 extra = {0.f, 0.f, 0.f, 0.f};
+    int y = yp - 1, x = xp - 1, ty = yp - ky, tx = xp - kx;
+    int ey = (y == 1 && ky == 0) ? 0 : ((y == s.H - 2 && ky == s.kh - 1) ? s.H - 1 : -1);
+    int ex = (x == 1 && kx == 0) ? 0 : ((x == s.W - 2 && kx == s.kw - 1) ? s.W - 1 : -1);
+    if (row_ok && (ey >= 0 || ex >= 0)) {
+        const bool in_y = (unsigned)ty < (unsigned)s.H, in_x = (unsigned)tx < (unsigned)s.W;
+        if (ey >= 0 && in_x) extra += load_dy4(dy, s, t, b, ey, tx, co);
+        if (ex >= 0 && in_y) extra += load_dy4(dy, s, t, b, ty, ex, co);
+        if (ey >= 0 && ex >= 0) extra += load_dy4(dy, s, t, b, ey, ex, co);
+    }
+    return extra;
+}
+
+template <bool FOLD>
+__device__ __forceinline__ f32x4 finalize(f32x4 v, bool ok, const f32x4& sc, const f32x4& sh, int relu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float u = v[j] * sc[j] + sh[j];
-            v[j] = t.in_relu ? fmaxf(u, 0.f) : u;
+    for (int j = 0; j < 4; ++j) {
+        float u = v[j];
+        if (FOLD) {
+            u = u * sc[j] + sh[j];
+            u = relu ? fmaxf(u, 0.f) : u;
         }
+        v[j] = ok ? u : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
     return v;
 }
 
-// IN_DGRAD: 4 output channels [co, co+4) of dY (x (act'(Y) if t.dact)) feeding input pixel (y,x) through tap
+// IN_DGRAD: 4 output channels [co, co+4) of dY (x act'(Y) if t.dact) feeding input pixel (y,x) through tap
 // (ky,kx): source (ty,tx) = ((y + pad - ky)/stride, (x + pad - kx)/stride) when divisible and in range.
 // yp = y + pad, xp = x + pad.  s.H/s.W are dY's spatial size here, s.Cin its channel count (= conv Cout).
 // PAD_REFLECT (ReflectionPad2d(1) + 3x3 valid conv): the gradient of the mirrored border rows/columns folds
 // back: input row 1 also receives what padded row 0 received (tap ky = 0 -> dY row 0), row H-2 what padded
-// row H+1 received (tap ky = 2 -> dY row H-1); same for columns.
+// row H+1 received (tap ky = 2 -> dY row H-1); same for columns.  Those extra terms (border pixels only, a
+// rare divergent branch) are returned already multiplied in `extra`.
 __device__ __forceinline__ f32x4 load_dy4(const float* __restrict__ dy, const ConvShape& s, const InXform& t, int b,
                                           int ty, int tx, int co) {
     size_t o = (((size_t)b * s.H + ty) * s.W + tx) * s.Cin + co;
@@ -158,59 +229,73 @@ __device__ __forceinline__ f32x4 load_dy4(const float* __restrict__ dy, const Co
     return v;
 }
 
-__device__ __forceinline__ f32x4 gather4_dgrad(const float* __restrict__ dy, const ConvShape& s, const InXform& t,
-                                               int b, int yp, int xp, int ky, int kx, int co, bool ok) {
+__device__ __forceinline__ f32x4 gather_dgrad_raw(const float* __restrict__ dy, const ConvShape& s, const InXform& t,
+                                                  int b, int yp, int xp, int ky, int kx, int co, bool& ok, f32x4& yv,
+                                                  f32x4& extra) {
     int ty = yp - ky, tx = xp - kx;
     if (s.stride == 2) {
         ok = ok && ((ty | tx) & 1) == 0;
         ty >>= 1;
         tx >>= 1;
     }
-    ok = ok && (unsigned)ty < (unsigned)s.H && (unsigned)tx < (unsigned)s.W;
-    f32x4 v = load_dy4(dy, s, t, b, clampi(ty, s.H), clampi(tx, s.W), co);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0.f;
+    const bool in_y = (unsigned)ty < (unsigned)s.H, in_x = (unsigned)tx < (unsigned)s.W;
+    const bool row_ok = ok;
+    ok = ok && in_y && in_x;
+    size_t o = (((size_t)b * s.H + clampi(ty, s.H)) * s.W + clampi(tx, s.W)) * s.Cin + co;
+    f32x4 v = *reinterpret_cast<const f32x4*>(dy + o);
+    if (t.dact) yv = *reinterpret_cast<const f32x4*>(t.aux + o);
+    extra = f32x4{0.f, 0.f, 0.f, 0.f};
     if (s.pad_mode == PAD_REFLECT) {
         // (yp, xp) = (y + 1, x + 1); rows/cols are the unpadded input's = dY's size
         int y = yp - 1, x = xp - 1;
         int ey = (y == 1 && ky == 0) ? 0 : ((y == s.H - 2 && ky == s.kh - 1) ? s.H - 1 : -1);
         int ex = (x == 1 && kx == 0) ? 0 : ((x == s.W - 2 && kx == s.kw - 1) ? s.W - 1 : -1);
-        bool in_y = (unsigned)ty < (unsigned)s.H, in_x = (unsigned)tx < (unsigned)s.W;
-        if (ey >= 0 || ex >= 0) {      // border pixels only (rare, divergent)
-            f32x4 e = {0.f, 0.f, 0.f, 0.f};
-            if (ey >= 0 && in_x) e += load_dy4(dy, s, t, b, ey, tx, co);
-            if (ex >= 0 && in_y) e += load_dy4(dy, s, t, b, ty, ex, co);
-            if (ey >= 0 && ex >= 0) e += load_dy4(dy, s, t, b, ey, ex, co);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += e[j];
+        if (row_ok && (ey >= 0 || ex >= 0)) {
+            if (ey >= 0 && in_x) extra += load_dy4(dy, s, t, b, ey, tx, co);
+            if (ex >= 0 && in_y) extra += load_dy4(dy, s, t, b, ty, ex, co);
+            if (ey >= 0 && ex >= 0) extra += load_dy4(dy, s, t, b, ey, ex, co);
         }
     }
     return v;
 }
 
+__device__ __forceinline__ f32x4 finalize_dgrad(f32x4 v, const f32x4& yv, const f32x4& extra, bool ok, int dact) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float u = dact ? v[j] * act_grad_from_out(yv[j], dact) : v[j];
+        v[j] = (ok ? u : 0.f) + extra[j];
+    }
+    return v;
+}
+
 // IN_PLANAR: k = (ci*kh + ky)*8 + kx (kx padded to 8); a 16-byte k-slice is 4 horizontally adjacent
-// pixels of one planar channel row.
-template <bool FOLD>
-__device__ __forceinline__ f32x4 gather4_planar(const float* __restrict__ x, const ConvShape& s, const InXform& t,
-                                                int b, int iy0, int ix0, int k, bool ok) {
+// pixels of one planar channel row.  mask4 bit e = element e is a real (in-image, kx < kw) sample.
+__device__ __forceinline__ f32x4 gather_planar_raw(const float* __restrict__ x, const ConvShape& s, int b, int iy0,
+                                                   int ix0, int k, bool ok, unsigned& mask4, int& ci_out) {
     int kx = k & 7, row = k >> 3;
     int ci = row / s.kh, ky = row - ci * s.kh;
     ci = min(ci, s.Cin - 1);
+    ci_out = ci;
     int iy = iy0 + ky;
     bool oky = ok && (unsigned)iy < (unsigned)s.H;
     const float* rowp = x + (((size_t)b * s.Cin + ci) * s.H + clampi(iy, s.H)) * s.W;
-    float sc = 1.f, sh = 0.f;
-    if (FOLD) {
-        sc = t.in_scale[ci];
-        sh = t.in_shift[ci];
-    }
     f32x4 v;
+    mask4 = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         int ix = ix0 + kx + e;
-        float u = rowp[clampi(ix, s.W)];
-        if (FOLD) u = u * sc + sh;
-        v[e] = (oky && (unsigned)ix < (unsigned)s.W && kx + e < s.kw) ? u : 0.f;
+        v[e] = rowp[clampi(ix, s.W)];
+        mask4 |= (oky && (unsigned)ix < (unsigned)s.W && kx + e < s.kw) ? (1u << e) : 0u;
+    }
+    return v;
+}
+
+template <bool FOLD>
+__device__ __forceinline__ f32x4 finalize_planar(f32x4 v, unsigned mask4, float sc, float sh) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float u = FOLD ? v[e] * sc + sh : v[e];
+        v[e] = ((mask4 >> e) & 1u) ? u : 0.f;
     }
     return v;
 }

@@ -14,6 +14,8 @@
 // BasicBlock convs), model/depthnet.py:64-90, model/layers.py:106-136, model/posenet_single.py:174-202.
 #include "conv_common.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace dvsconv;
 
@@ -28,23 +30,45 @@ struct FwdParams {
     int act;
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+// NBUF = 2: double-buffered LDS, one barrier per K-step (2 workgroups / CU for the 128-wide tiles);
+// NBUF = 1: one LDS buffer, the next stage waits in registers, two barriers per K-step but half the LDS,
+//           so twice as many workgroups (waves per SIMD) hide each other's gather / barrier phases.
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_VECS = BM / 32, B_VECS = BN / 32;       // 16-byte vectors per thread per stage
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;                // [2][BN][LDK]
+    float* As = smem;                               // [NBUF][BM][LDK]
+    float* Bs = smem + NBUF * BM * LDK;             // [NBUF][BN][LDK]
 
-    const ConvShape& s = p.s;
+    ConvShape s = p.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int M = s.B * s.Ho * s.Wo;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int c4 = (tid & 7) * 4, r0 = tid >> 3;            // my k-offset inside a stage, my first row
 
-    // output pixels of my A rows
+    // Row space.  Forward: output pixels.  Data gradient: input pixels -- for a stride-2 conv they are split
+    // into the 4 parity classes (blockIdx.z) of (y + pad, x + pad): a class only ever meets the taps of its
+    // own parity (ky = py + 2 jy), so the empty 3/4 of the strided im2col matrix is never multiplied.
+    int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0, kw_full = s.kw;
+    if (MODE == IN_DGRAD && s.stride == 2) {
+        const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+        oy0 = (py - s.pad) & 1;
+        ox0 = (px - s.pad) & 1;
+        Hr = (s.Ho - oy0 + 1) >> 1;
+        Wr = (s.Wo - ox0 + 1) >> 1;
+        rstep = 2;
+        ky0 = py;
+        kx0 = px;
+        s.kh = py < s.kh ? (s.kh - py + 1) >> 1 : 0;          // taps of this class
+        s.kw = px < s.kw ? (s.kw - px + 1) >> 1 : 0;
+        s.Ktot = s.kh * s.kw * s.Cin;
+    }
+    const int M = s.B * Hr * Wr;
+    if (m0 >= M) return;
+
+    // pixels of my A rows
     int a_b[A_VECS], a_iy[A_VECS], a_ix[A_VECS];
     bool a_ok[A_VECS];
 #pragma unroll
@@ -52,12 +76,12 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
         int m = m0 + r0 + 32 * j;
         a_ok[j] = m < M;
         m = min(m, M - 1);
-        int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
-        int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
+        int oy = rem / Wr, ox = rem - oy * Wr;
         a_b[j] = b;
-        if (MODE == IN_DGRAD) {      // rows are input pixels; the gather subtracts the tap
-            a_iy[j] = oy + s.pad;
-            a_ix[j] = ox + s.pad;
+        if (MODE == IN_DGRAD) {      // the gather subtracts the tap from (y + pad, x + pad)
+            a_iy[j] = oy * rstep + oy0 + s.pad;
+            a_ix[j] = ox * rstep + ox0 + s.pad;
         } else {
             a_iy[j] = oy * s.stride - s.pad;
             a_ix[j] = ox * s.stride - s.pad;
@@ -70,42 +94,83 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     for (int j = 0; j < B_VECS; ++j) {
         int n = n0 + r0 + 32 * j;
         b_ok[j] = n < s.Cout;
-        b_ptr[j] = p.w + (size_t)min(n, s.Cout - 1) * s.Ktot;
+        b_ptr[j] = p.w + (size_t)min(n, s.Cout - 1) * p.s.Ktot;
     }
 
     KPos kp;
     kp.init(c4, s);
-    f32x4 ra[A_VECS], rb[B_VECS];
-    auto load_stage = [&]() {      // loads the stage kp points at, then advances kp
+    // stage registers: raw loads + validity; zeros / folds are applied in store_stage, AFTER the MFMAs
+    f32x4 ra[A_VECS], rb[B_VECS], ry[A_VECS], re[A_VECS], fsc, fsh;
+    bool ra_ok[A_VECS], rb_ok;
+    unsigned ra_mask[A_VECS];
+    float psc = 1.f, psh = 0.f;
+    int t_off[A_VECS], t_off2[A_VECS], cur_tap = -1;       // per-tap cache of pixel offsets / validity
+    bool t_ok[A_VECS];
+    auto load_stage = [&]() {      // issues the loads of the stage kp points at, then advances kp
         const bool k_ok = kp.k < s.Ktot;
-        const int kc = min(kp.k, s.Ktot - 4);
+        int kc = min(kp.k, p.s.Ktot - 4);
+        const int ky = ky0 + rstep * kp.ky, kx = kx0 + rstep * kp.kx;       // actual tap (parity classes skip taps)
+        if (MODE == IN_DGRAD) kc = k_ok ? (ky * kw_full + kx) * s.Cin + kp.ci : 0;
+        // per-tap work (padding, clamping, pixel offsets) only when my tap changes: every Cin/32 stages
+        const int tap = ky * kw_full + kx;
+        if (MODE != IN_PLANAR && tap != cur_tap) {
+            cur_tap = tap;
+#pragma unroll
+            for (int j = 0; j < A_VECS; ++j) {
+                bool ok = a_ok[j];
+                if (MODE == IN_DGRAD) dgrad_tap_setup(p.s, a_b[j], a_iy[j], a_ix[j], ky, kx, ok, t_off[j]);
+                else tap_setup<MODE>(s, p.t, a_b[j], a_iy[j] + kp.ky, a_ix[j] + kp.kx, ok, t_off[j], t_off2[j]);
+                t_ok[j] = ok;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < A_VECS; ++j) {
-            if (MODE == IN_PLANAR)
-                ra[j] = gather4_planar<FOLD>(p.x, s, p.t, a_b[j], a_iy[j], a_ix[j], kc, a_ok[j] && k_ok);
-            else if (MODE == IN_DGRAD)
-                ra[j] = gather4_dgrad(p.x, s, p.t, a_b[j], a_iy[j], a_ix[j], kp.ky, kp.kx, kp.ci, a_ok[j] && k_ok);
-            else
-                ra[j] = gather4<MODE, FOLD>(p.x, s, p.t, a_b[j], a_iy[j] + kp.ky, a_ix[j] + kp.kx, kp.ci,
-                                            a_ok[j] && k_ok);
+            if (MODE == IN_PLANAR) {
+                int ci;
+                ra[j] = gather_planar_raw(p.x, s, a_b[j], a_iy[j], a_ix[j], kc, a_ok[j] && k_ok, ra_mask[j], ci);
+                if (FOLD && j == 0) {
+                    psc = p.t.in_scale[ci];
+                    psh = p.t.in_shift[ci];
+                }
+            } else if (MODE == IN_DGRAD) {
+                ra[j] = *reinterpret_cast<const f32x4*>(p.x + (t_off[j] + kp.ci));
+                if (p.t.dact) ry[j] = *reinterpret_cast<const f32x4*>(p.t.aux + (t_off[j] + kp.ci));
+                re[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.s.pad_mode == PAD_REFLECT)
+                    re[j] = dgrad_reflect_extra(p.x, p.s, p.t, a_b[j], a_iy[j], a_ix[j], ky, kx, kp.ci, a_ok[j] && k_ok);
+                ra_ok[j] = t_ok[j] && k_ok;
+            } else {
+                ra[j] = load_tap4<MODE>(p.x, p.t, t_off[j], t_off2[j], kp.ci);
+                ra_ok[j] = t_ok[j] && k_ok;
+            }
+        }
+        if (FOLD && MODE != IN_PLANAR) {
+            fsc = *reinterpret_cast<const f32x4*>(p.t.in_scale + kp.ci);
+            fsh = *reinterpret_cast<const f32x4*>(p.t.in_shift + kp.ci);
         }
 #pragma unroll
-        for (int j = 0; j < B_VECS; ++j) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(b_ptr[j] + kc);
-            const bool ok = b_ok[j] && k_ok;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rb[j][e] = ok ? v[e] : 0.f;
-        }
+        for (int j = 0; j < B_VECS; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j] + kc);
+        rb_ok = k_ok;
         if (MODE == IN_PLANAR) kp.k += BK;
         else kp.advance(s);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < A_VECS; ++j)
-            *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * j) * LDK + c4) = ra[j];
+        for (int j = 0; j < A_VECS; ++j) {
+            f32x4 v;
+            if (MODE == IN_PLANAR) v = finalize_planar<FOLD>(ra[j], ra_mask[j], psc, psh);
+            else if (MODE == IN_DGRAD) v = finalize_dgrad(ra[j], ry[j], re[j], ra_ok[j], p.t.dact);
+            else v = finalize<FOLD>(ra[j], ra_ok[j], fsc, fsh, p.t.in_relu);
+            *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * j) * LDK + c4) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < B_VECS; ++j)
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * j) * LDK + c4) = rb[j];
+        for (int j = 0; j < B_VECS; ++j) {
+            const bool ok = b_ok[j] && rb_ok;
+            f32x4 v = rb[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * j) * LDK + c4) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -122,10 +187,11 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     __syncthreads();
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+        const int buf = (NBUF == 2) ? (kt & 1) : 0;
         if (kt + 1 < KT) load_stage();                // global loads in flight during the MFMAs
         mfma_stage<TM, TN>(As + buf * BM * LDK, Bs + buf * BN * LDK, wm * TM * 32, wn * TN * 32, lane, acc);
-        if (kt + 1 < KT) store_stage(buf ^ 1);
+        if (NBUF == 1) __syncthreads();               // everyone is done reading the single buffer
+        if (kt + 1 < KT) store_stage((NBUF == 2) ? (buf ^ 1) : 0);
         __syncthreads();
     }
 
@@ -147,7 +213,13 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
                 if (m < M && n_ok) {
                     ssum += v;
                     ssq += v * v;
-                    p.y[(size_t)m * s.Cout + n] = apply_act(v + bv, p.act);
+                    size_t pix = (size_t)m;
+                    if (MODE == IN_DGRAD && rstep == 2) {       // parity-class row -> pixel of the full grid
+                        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
+                        int oy = rem / Wr, ox = rem - oy * Wr;
+                        pix = ((size_t)b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
+                    }
+                    p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
                 }
             }
         }
@@ -162,18 +234,43 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     }
 }
 
+int conv_nbuf() {
+    static int v = [] {
+        const char* e = getenv("DVS_CONV_NBUF");
+        return (e && e[0] == '2') ? 2 : 1;
+    }();
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
+void launch_buf(const FwdParams& p, hipStream_t st, int slot);
+
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(const FwdParams& p, hipStream_t st, int slot) {
+    if (conv_nbuf() == 2) launch_buf<BM, BN, WM, WN, MODE, FOLD, 2>(p, st, slot);
+    else launch_buf<BM, BN, WM, WN, MODE, FOLD, 1>(p, st, slot);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
+void launch_buf(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
     dim3 grid((M + BM - 1) / BM, (p.s.Cout + BN - 1) / BN);
-    size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-    auto kern = conv_fwd_kernel<BM, BN, WM, WN, MODE, FOLD>;
+    if (MODE == IN_DGRAD && p.s.stride == 2) {      // 4 parity classes of input pixels (see the kernel)
+        int mc = p.s.B * ((p.s.Ho + 1) / 2) * ((p.s.Wo + 1) / 2);
+        grid = dim3((mc + BM - 1) / BM, (p.s.Cout + BN - 1) / BN, 4);
+    }
+    size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
+    auto kern = conv_fwd_kernel<BM, BN, WM, WN, MODE, FOLD, NBUF>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dvs::ProfScope prof(slot, st);
+    // algorithmic flops of the convolution (IN_PLANAR: the 7 real taps of a row, not the 8 padded ones)
+    const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
+    const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;   // strided taps are empty
+    prof.work(2.0 * M * p.s.Cout * k_real * eff);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
 }
 
@@ -230,6 +327,8 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 4 && d->W >= 4),
                 "dvs_conv2d_dgrad: reflect mode is ReflectionPad2d(1) + 3x3 stride 1 only");
     DVS_REQUIRE(!dact || y_out, "dvs_conv2d_dgrad: activation gradient needs the forward output");
+    DVS_REQUIRE((double)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) < 2147483648.0,
+                "dvs_conv2d_dgrad: tensors must have fewer than 2^31 elements (32-bit gather offsets)");
     FwdParams p{};
     p.x = dy; p.w = wt; p.y = dx;
     ConvShape& s = p.s;
@@ -260,14 +359,18 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     s.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
     s.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     DVS_REQUIRE(s.Ho > 0 && s.Wo > 0, "dvs_conv2d_fwd: empty output");
+    DVS_REQUIRE((double)d->B * d->H * d->W * d->Cin < 2147483648.0 && (double)d->B * s.Ho * s.Wo * d->Cout < 2147483648.0,
+                "dvs_conv2d_fwd: tensors must have fewer than 2^31 elements (32-bit gather offsets)");
     DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad < d->H && d->pad < d->W), "dvs_conv2d_fwd: reflect pad too large");
     int planar = 0;
     if (f) {
         p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
         p.t.in_relu = f->in_relu; planar = f->nchw_planar;
         p.act = f->act; p.stats = f->stats;
-        DVS_REQUIRE(!(f->x2) || (f->C1 > 0 && f->C1 < d->Cin && (f->C1 % BK) == 0 && (d->H & 1) == 0 && (d->W & 1) == 0),
-                    "dvs_conv2d_fwd: upsample+concat needs C1 %% 32 == 0 and even H, W");
+        // C1 == Cin: upsample only (x2 is never read); otherwise the concat boundary must not split a 32-k stage
+        DVS_REQUIRE(!(f->x2) || (f->C1 > 0 && (d->H & 1) == 0 && (d->W & 1) == 0 &&
+                                 ((f->C1 == d->Cin && (f->C1 & 3) == 0) || (f->C1 < d->Cin && (f->C1 % BK) == 0))),
+                    "dvs_conv2d_fwd: upsample+concat needs C1 %% 32 == 0 (or C1 == Cin) and even H, W");
         DVS_REQUIRE(!(f->x2 && planar), "dvs_conv2d_fwd: planar input cannot be concatenated");
         DVS_REQUIRE((f->in_scale == nullptr) == (f->in_shift == nullptr), "dvs_conv2d_fwd: in_scale/in_shift come together");
     }

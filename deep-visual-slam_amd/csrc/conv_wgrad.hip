@@ -63,22 +63,24 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
         kx = tap - ky * s.kw;
     }
 
-    f32x4 rd[D_VECS], rx[X_VECS], bsum = {0.f, 0.f, 0.f, 0.f};
+    // stage registers: raw loads + validity; zeros / folds are applied in store_stage, AFTER the MFMAs
+    f32x4 rd[D_VECS], rdy[D_VECS], rx[X_VECS], bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fsc = {1.f, 1.f, 1.f, 1.f}, fsh = {0.f, 0.f, 0.f, 0.f};
+    bool rd_ok[D_VECS], rx_ok[X_VECS];
+    unsigned rx_mask[X_VECS];
+    float psc = 1.f, psh = 0.f;
+    if (FOLD && MODE != IN_PLANAR) {     // my k-slice (hence its channels) is fixed for the whole kernel
+        fsc = *reinterpret_cast<const f32x4*>(p.t.in_scale + ci);
+        fsh = *reinterpret_cast<const f32x4*>(p.t.in_shift + ci);
+    }
     auto load_stage = [&](int mb) {
 #pragma unroll
         for (int j = 0; j < D_VECS; ++j) {
             int m = mb + d_p0 + (NT / DV) * j;
-            bool ok = m < m_end && co_ok;
+            rd_ok[j] = m < m_end && co_ok;
             size_t o = (size_t)min(m, M - 1) * s.Cout + min(co, s.Cout - 4);
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + o);
-            if (p.t.dact) {
-                f32x4 y = *reinterpret_cast<const f32x4*>(p.t.aux + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(y[e], p.t.dact);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            rd[j] = v;
+            rd[j] = *reinterpret_cast<const f32x4*>(p.dy + o);
+            if (p.t.dact) rdy[j] = *reinterpret_cast<const f32x4*>(p.t.aux + o);
         }
 #pragma unroll
         for (int j = 0; j < X_VECS; ++j) {
@@ -88,18 +90,38 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
             int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
             int oy = rem / s.Wo, ox = rem - oy * s.Wo;
             int iy = oy * s.stride - s.pad, ix = ox * s.stride - s.pad;
-            if (MODE == IN_PLANAR) rx[j] = gather4_planar<FOLD>(p.x, s, p.t, b, iy, ix, min(k, s.Ktot - 4), ok);
-            else rx[j] = gather4<MODE, FOLD>(p.x, s, p.t, b, iy + ky, ix + kx, ci, ok);
+            if (MODE == IN_PLANAR) {
+                int pci;
+                rx[j] = gather_planar_raw(p.x, s, b, iy, ix, min(k, s.Ktot - 4), ok, rx_mask[j], pci);
+                if (FOLD && j == 0) {
+                    psc = p.t.in_scale[pci];
+                    psh = p.t.in_shift[pci];
+                }
+            } else {
+                rx[j] = gather_raw<MODE>(p.x, s, p.t, b, iy + ky, ix + kx, ci, ok);
+            }
+            rx_ok[j] = ok;
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < D_VECS; ++j) {
-            *reinterpret_cast<f32x4*>(&Ds[buf][d_p0 + (NT / DV) * j][d_c]) = rd[j];
-            bsum += rd[j];
+            f32x4 v = rd[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float u = p.t.dact ? v[e] * act_grad_from_out(rdy[j][e], p.t.dact) : v[e];
+                v[e] = rd_ok[j] ? u : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&Ds[buf][d_p0 + (NT / DV) * j][d_c]) = v;
+            bsum += v;
         }
 #pragma unroll
-        for (int j = 0; j < X_VECS; ++j) *reinterpret_cast<f32x4*>(&Xs[buf][x_p0 + (NT / XV) * j][x_c]) = rx[j];
+        for (int j = 0; j < X_VECS; ++j) {
+            f32x4 v;
+            if (MODE == IN_PLANAR) v = finalize_planar<FOLD>(rx[j], rx_mask[j], psc, psh);
+            else v = finalize<FOLD>(rx[j], rx_ok[j], fsc, fsh, p.t.in_relu);
+            *reinterpret_cast<f32x4*>(&Xs[buf][x_p0 + (NT / XV) * j][x_c]) = v;
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -176,6 +198,8 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     p.m_per_split = mps;
     dim3 grid((p.s.Cout + BM - 1) / BM, (p.s.Ktot + BN - 1) / BN, splits);
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
+    const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
+    prof.work(2.0 * M * p.s.Cout * k_real);
     hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD>), grid, dim3(NT), 0, st, p);
 }
 

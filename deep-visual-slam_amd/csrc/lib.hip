@@ -31,6 +31,7 @@ std::atomic<bool> g_on{false};
 std::vector<Pair> g_pairs[SLOT_COUNT];
 double g_ms[SLOT_COUNT];
 long g_n[SLOT_COUNT];
+double g_work[SLOT_COUNT];   // algorithmic flops (MFMA kernels) or bytes (HBM kernels) of the recorded launches
 const char* kSlotNames[SLOT_COUNT] = {"chain_fwd_kernel", "chain_bwd_kernel", "adam_kernel", "conv_fwd_kernel",
                                       "conv_dgrad_kernel", "conv_wgrad_kernel", "bn_fwd_kernel", "bn_bwd_kernel"};
 
@@ -58,6 +59,11 @@ void prof_begin(int, hipStream_t st, hipEvent_t* start) {
     (void)hipEventRecord(*start, st);
 }
 
+void prof_work(int slot, double work) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_work[slot] += work;
+}
+
 void prof_end(int slot, hipStream_t st, hipEvent_t start) {
     if (!start) return;
     hipEvent_t stop;
@@ -80,12 +86,20 @@ int dvs_profile_enable(int on) {
         dvs::drain_locked(s);
         dvs::g_ms[s] = 0.0;
         dvs::g_n[s] = 0;
+        dvs::g_work[s] = 0.0;
     }
     dvs::g_on.store(on != 0);
     return DVS_OK;
 }
 
 int dvs_profile_slots(void) { return dvs::SLOT_COUNT; }
+
+int dvs_profile_work(int slot, double* work) {
+    DVS_REQUIRE(slot >= 0 && slot < dvs::SLOT_COUNT && work, "dvs_profile_work: bad argument");
+    std::lock_guard<std::mutex> lk(dvs::g_mu);
+    *work = dvs::g_work[slot];
+    return DVS_OK;
+}
 
 const char* dvs_profile_slot_name(int slot) {
     return (slot >= 0 && slot < dvs::SLOT_COUNT) ? dvs::kSlotNames[slot] : "";

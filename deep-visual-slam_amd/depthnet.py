@@ -36,6 +36,8 @@ class DepthNet(nn.Module):
             self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
+        # weights live as [Cout][kh][kw][Cin] in memory (same logical shapes / state_dict)
+        self.to(memory_format=torch.channels_last)
 
     def forward(self, input_data) -> dict:
         input_features = self.encoder(input_data)
@@ -43,11 +45,9 @@ class DepthNet(nn.Module):
         x = input_features[-1]
         for i in range(4, -1, -1):
             x = self.convs[("upconv", i, 0)](x)
-            x = [upsample(x)]
-            if self.use_skips and i > 0:
-                x += [input_features[i - 1]]
-            x = torch.cat(x, 1)
-            x = self.convs[("upconv", i, 1)](x)
+            # upsample(x) ; cat skip ; ConvBlock -- one fused gather + conv (model/depthnet.py:80-85)
+            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+            x = self.convs[("upconv", i, 1)](x, skip=skip, upsample=True)
             if i in self.scales:
-                self.outputs[("disp", i)] = torch.sigmoid(self.convs[("dispconv", i)](x))
+                self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")
         return self.outputs

@@ -50,9 +50,19 @@ class FlatParams:
         self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
         for p, o in zip(self.tensors, self.offsets):
             n = p.numel()
-            self.params[o:o + n].copy_(p.data.reshape(-1))
-            p.data = self.params[o:o + n].view(p.shape)
-            p.grad = self.grads[o:o + n].view(p.shape)
+            self._view(self.params, p, o).copy_(p.data)
+            p.data = self._view(self.params, p, o)
+            p.grad = self._view(self.grads, p, o)
+
+    @staticmethod
+    def _view(flat, p, o):
+        """Slot view with the parameter's logical shape.  Convolution weights are stored [Cout][kh][kw][Cin]
+        (torch channels_last), the [N][K] operand layout of the implicit-GEMM kernels."""
+        n = p.numel()
+        if p.dim() == 4:
+            co, ci, kh, kw = p.shape
+            return flat[o:o + n].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat[o:o + n].view(p.shape)
 
     def zero_grad(self):
         self.grads.zero_()
@@ -61,7 +71,7 @@ class FlatParams:
         """Re-point .grad at the arena (e.g. after a caller ran zero_grad(set_to_none=True))."""
         for p, o in zip(self.tensors, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
-                p.grad = self.grads[o:o + p.numel()].view(p.shape)
+                p.grad = self._view(self.grads, p, o)
 
 
 class GradSync:
@@ -151,12 +161,13 @@ def profile_enable(on=True):
 
 
 def profile_read():
-    """{kernel_name: (total_ms, launches)} for every slot that recorded launches."""
+    """{kernel_name: (total_ms, launches, algorithmic_work)} for every slot that recorded launches."""
     l = _lib.lib()
     out = {}
     for s in range(l.dvs_profile_slots()):
-        ms, n = C.c_double(), C.c_long()
+        ms, n, w = C.c_double(), C.c_long(), C.c_double()
         check(l.dvs_profile_read(s, C.byref(ms), C.byref(n)), "dvs_profile_read")
+        check(l.dvs_profile_work(s, C.byref(w)), "dvs_profile_work")
         if n.value:
-            out[l.dvs_profile_slot_name(s).decode()] = (ms.value, n.value)
+            out[l.dvs_profile_slot_name(s).decode()] = (ms.value, n.value, w.value)
     return out

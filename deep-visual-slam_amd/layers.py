@@ -43,10 +43,11 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x):
-        if self.use_refl:
-            return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, 0, reflect_pad=1)
-        return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, 1)
+    def forward(self, x, act=None, skip=None, upsample=False):
+        """act / skip / upsample are fusion hooks of this port (one launch for upsample + concat + pad + conv
+        + activation); plain `conv(x)` is the reference call."""
+        pad = dict(reflect_pad=1) if self.use_refl else dict(padding=1)
+        return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, act=act, x2=skip, upsample=upsample, **pad)
 
 
 class ConvBlock(nn.Module):
@@ -57,8 +58,10 @@ class ConvBlock(nn.Module):
         self.conv = Conv3x3(in_channels, out_channels)
         self.nonlin = nn.ELU(inplace=True)
 
-    def forward(self, x):
-        return nn_ops.elu(self.conv(x))
+    def forward(self, x, skip=None, upsample=False):
+        """ELU(conv(x)); with `skip`/`upsample` the input is cat([upsample(x), skip], 1) / upsample(x)
+        (model/depthnet.py:79-85) gathered inside the convolution."""
+        return self.conv(x, act="elu", skip=skip, upsample=upsample)
 
 
 class BackprojectDepth(nn.Module):

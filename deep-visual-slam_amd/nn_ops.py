@@ -1,9 +1,11 @@
 """Network primitives used by ResnetEncoder / DepthNet / PoseNet.
 
-Every primitive is GPU-only.  The convolution engine is selected by DVS_CONV_BACKEND:
-  "hip"    hand-written gfx950 implicit-GEMM kernels of libdvslam_hip.so (default where a kernel
-           exists for the shape);
-  "miopen" PyTorch-ROCm's library convolution -- bring-up/A-B baseline only, never the CPU.
+Every primitive is GPU-only and keeps activations in channels_last (NHWC) memory.  The convolution
+engine is selected by DVS_CONV_BACKEND:
+  "hip"    (default) hand-written gfx950 implicit-GEMM kernels of libdvslam_hip.so wherever they cover
+           the shape (everything except the 1- and 6-channel heads);
+  "miopen" PyTorch-ROCm's library convolution composed with eager pad / upsample / cat / activation --
+           bring-up and A/B baseline only.  Neither choice ever runs on the CPU.
 """
 import os
 
@@ -11,6 +13,10 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
+from . import conv as _conv
+
+CL = torch.channels_last
+_ACT = {None: lambda v: v, "relu": F.relu, "elu": F.elu, "sigmoid": torch.sigmoid}
 
 
 def _require_gpu(x, who):
@@ -23,15 +29,28 @@ def conv_backend():
     return os.environ.get("DVS_CONV_BACKEND", "hip")
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0):
-    """Convolution with optional ReflectionPad2d(reflect_pad) in front (model/layers.py:121-136)."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
+           planar_norm=None):
+    """act(conv(pad(input), weight) + bias) where input is x, upsample2x(x) (upsample=True) or
+    cat([upsample2x(x), x2], 1) (x2 given); reflect_pad=1 puts ReflectionPad2d(1) in front
+    (model/layers.py:121-136); planar_norm=(scale, shift) is the encoder's conv1 on the raw planar image
+    with (x - 0.45) / 0.225 folded in (model/resnet_encoder.py:102-103)."""
     _require_gpu(x, "conv2d")
-    from . import conv as _conv
-    if conv_backend() == "hip" and _conv.supported(x, weight, stride, padding, reflect_pad):
-        return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad)
+    planar = planar_norm is not None
+    if conv_backend() == "hip" and _conv.supported(x, weight, x2, planar, upsample):
+        return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
+                            planar_norm=planar_norm)
+    # library path (also serves the 1- and 6-channel heads)
+    if planar:
+        sc, sh = planar_norm
+        x = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if upsample or x2 is not None:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if x2 is not None:
+        x = torch.cat([x, x2], 1)
     if reflect_pad:
         x = F.pad(x, (reflect_pad,) * 4, mode="reflect")
-    return F.conv2d(x, weight, bias, stride, padding)
+    return _ACT[act](F.conv2d(x, weight, bias, stride, padding))
 
 
 def batch_norm(x, bn, relu=False, residual=None):
@@ -50,10 +69,6 @@ def batch_norm(x, bn, relu=False, residual=None):
 def max_pool_3x3_s2(x):
     _require_gpu(x, "max_pool")
     return F.max_pool2d(x, 3, 2, 1)
-
-
-def elu(x):
-    return F.elu(x, inplace=True)
 
 
 def upsample_nearest2x(x):

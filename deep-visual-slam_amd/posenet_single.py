@@ -29,16 +29,16 @@ class PoseNet(nn.Module):
         self.convs[("pose", 2)] = nn.Conv2d(256, 6, 1)
         self.relu = nn.ReLU()
         self.net = nn.ModuleList(list(self.convs.values()))
+        # weights live as [Cout][kh][kw][Cin] in memory (same logical shapes / state_dict)
+        self.to(memory_format=torch.channels_last)
 
     def forward(self, input_images):
         feature = self.encoder(input_images)
         sq = self.convs["squeeze"]
-        out = F.relu(nn_ops.conv2d(feature[-1], sq.weight, sq.bias, 1, 0))
+        out = nn_ops.conv2d(feature[-1], sq.weight, sq.bias, 1, 0, act="relu")
         for i in range(3):
             c = self.convs[("pose", i)]
-            out = nn_ops.conv2d(out, c.weight, c.bias, c.stride[0], c.padding[0])
-            if i != 2:
-                out = F.relu(out)
+            out = nn_ops.conv2d(out, c.weight, c.bias, c.stride[0], c.padding[0], act="relu" if i != 2 else None)
         out = out.mean(3).mean(2)
         out = 0.01 * out.view(-1, 1, 1, 6)
         return out[..., :3], out[..., 3:]

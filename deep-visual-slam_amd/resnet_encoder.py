@@ -112,8 +112,11 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         self.features = []
-        x = (input_image - 0.45) / 0.225
-        x = nn_ops.conv2d(x, e.conv1.weight, None, 2, 3)
+        # (x - 0.45) / 0.225 is folded into conv1's gather of the planar image (resnet_encoder.py:102-103)
+        nch = input_image.shape[1]
+        scale = torch.full((nch,), 1.0 / 0.225, device=input_image.device)
+        shift = torch.full((nch,), -0.45 / 0.225, device=input_image.device)
+        x = nn_ops.conv2d(input_image, e.conv1.weight, None, 2, 3, planar_norm=(scale, shift))
         self.features.append(nn_ops.batch_norm(x, e.bn1, relu=True))
         x = nn_ops.max_pool_3x3_s2(self.features[-1])
         for layer in (e.layer1, e.layer2, e.layer3, e.layer4):

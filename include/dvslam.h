@@ -54,6 +54,9 @@ int dvs_profile_enable(int on);
 int dvs_profile_slots(void);
 const char* dvs_profile_slot_name(int slot);
 int dvs_profile_read(int slot, double* total_ms, long* launches);
+/* Algorithmic work of the launches recorded in a slot: flops for the MFMA kernels (2*M*N*K of each
+ * convolution), 0 for kernels whose byte count the caller derives from the problem size. */
+int dvs_profile_work(int slot, double* work);
 
 /* ---------------------------------------------------------------------------------------------
  * a13  Adam over a flat fp32 arena: one pass replaces torch.optim.Adam(params, lr) + zero_grad of
