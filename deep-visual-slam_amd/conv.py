@@ -146,18 +146,22 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, x2, opts):
-        stride, pad, reflect, act, planar, scale, shift = opts
+        stride, pad, reflect, act, planar, scale, shift, want_stats = opts
+        stats = torch.zeros(2, weight.shape[0], device=x.device, dtype=torch.float32) if want_stats else None
         y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
-                           nchw_planar=planar)
-        ctx.opts = opts
+                           nchw_planar=planar, stats=stats)
+        ctx.opts = opts[:7]
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
         ctx.up_only = x2 is UPSAMPLE_ONLY
         ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x, weight, x2, y = ctx.saved_tensors
         stride, pad, reflect, act, planar, scale, shift = ctx.opts
         dx = dx2 = dw = db = None
@@ -199,7 +203,7 @@ def supported(x, weight, x2=None, planar=False, upsample=False):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
-           planar_norm=None):
+           planar_norm=None, want_stats=False):
     """Differentiable fused convolution.  reflect_pad=1 means ReflectionPad2d(1) in front of a valid conv;
     x2 / upsample select the decoder's upsample(+concat) gather; planar_norm=(scale, shift) selects the
     encoder-conv1 path (planar image in, normalisation fused)."""
@@ -208,4 +212,5 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     pad, reflect = (reflect_pad, True) if reflect_pad else (padding, False)
     if x2 is None and upsample:
         x2 = UPSAMPLE_ONLY
-    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift))
+    # want_stats: also return [2][Cout] per-channel sum / sum of squares of y (BatchNorm batch statistics)
+    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift, bool(want_stats)))

@@ -324,7 +324,7 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     DVS_REQUIRE(dy && wt && dx && d, "dvs_conv2d_dgrad: null pointer");
     DVS_REQUIRE(d->stride == 1 || d->stride == 2, "dvs_conv2d_dgrad: stride %d (1 or 2 supported)", d->stride);
     DVS_REQUIRE((d->Cout & 3) == 0 && (d->Cin & 3) == 0, "dvs_conv2d_dgrad: channel counts must be multiples of 4");
-    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 4 && d->W >= 4),
+    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 2 && d->W >= 2),
                 "dvs_conv2d_dgrad: reflect mode is ReflectionPad2d(1) + 3x3 stride 1 only");
     DVS_REQUIRE(!dact || y_out, "dvs_conv2d_dgrad: activation gradient needs the forward output");
     DVS_REQUIRE((double)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) < 2147483648.0,

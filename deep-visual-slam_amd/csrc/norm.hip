@@ -1,0 +1,260 @@
+// a1: training-mode BatchNorm2d (+ residual add, + ReLU) of the ResNet encoder on NHWC activations.
+//
+// The batch statistics come for free from the convolution epilogue (per-channel sum / sum of squares,
+// conv_fwd.hip); what is left of nn.BatchNorm2d is
+//   dvs_bn_finalize      C lanes: mean / inv-std, folded scale & shift, running-stat update
+//   dvs_bn_apply_fwd     one HBM pass: z = relu(y * scale + shift [+ residual or + its own folded BN])
+//   dvs_bn_bwd_reduce    one pass: du = dz * [z > 0], per-channel sum(du), sum(du * xhat)
+//   dvs_bn_bwd_apply     one pass: dy = gamma * invstd * (du - mean(du) - xhat * mean(du * xhat))
+// replacing the BasicBlock tail bn -> (+identity) -> relu of torchvision's ResNet as used by
+// model/resnet_encoder.py:100-111 (about 10 eager kernels per block, forward + backward).
+// All kernels are HBM-bound: 16-byte accesses, a lane owns 4 consecutive channels of a pixel.
+#include "common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int NT = 256;
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean = stats[c] / count;
+    float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);     // biased, as used for normalisation
+    float invstd = rsqrtf(var + eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - mean * g * invstd;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+        float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// z = act(y * sc + sh [+ r * rsc + rsh]); n4 = number of float4 (M * C / 4); C % 4 == 0
+__global__ __launch_bounds__(NT) void bn_apply_fwd_kernel(const float* __restrict__ y, const float* __restrict__ sc,
+                                                          const float* __restrict__ sh, const float* __restrict__ r,
+                                                          const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                                          float* __restrict__ z, size_t n4, int C, int relu) {
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        int c = (int)((i * 4) % C);
+        f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 s = *reinterpret_cast<const f32x4*>(sc + c), t = *reinterpret_cast<const f32x4*>(sh + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * s[j] + t[j];
+        if (r) {
+            f32x4 u = reinterpret_cast<const f32x4*>(r)[i];
+            if (rsc) {
+                f32x4 s2 = *reinterpret_cast<const f32x4*>(rsc + c), t2 = *reinterpret_cast<const f32x4*>(rsh + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = u[j] * s2[j] + t2[j];
+            }
+            v += u;
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        reinterpret_cast<f32x4*>(z)[i] = v;
+    }
+}
+
+// Column reduction over pixels.  A workgroup owns rows [blockIdx.x * rows_per_block, ...): lane -> (row lane,
+// 4-channel vector); sums[0][c] += sum du, sums[1][c] += sum du * xhat; optionally writes du.
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ du_out,
+                                                           float* __restrict__ sums, int M, int C, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
+    const int cv = C / 4, tid = threadIdx.x;
+    const int rl = tid / cv, c = (tid % cv) * 4, rlanes = NT / cv;     // cv = C/4 divides 256 (host-checked)
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        constexpr int U = 4;                                            // rows in flight per lane
+        for (int r = r0 + rl; r < r1; r += rlanes * U) {
+            f32x4 g[U], zz[U], yy[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                               // issue every load first
+                int ru = r + u * rlanes;
+                ok[u] = ru < r1;
+                size_t o = ((size_t)min(ru, r1 - 1) * cv) + (tid % cv);
+                g[u] = reinterpret_cast<const f32x4*>(dz)[o];
+                yy[u] = reinterpret_cast<const f32x4*>(y)[o];
+                if (z) zz[u] = reinterpret_cast<const f32x4*>(z)[o];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                size_t o = ((size_t)(r + u * rlanes) * cv) + (tid % cv);
+                if (z) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[u][j] = zz[u][j] > 0.f ? g[u][j] : 0.f;
+                }
+                if (du_out) reinterpret_cast<f32x4*>(du_out)[o] = g[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] += g[u][j];
+                    b[j] += g[u][j] * (yy[u][j] - mu[j]) * is[j];
+                }
+            }
+        }
+    }
+    // reduce over the row lanes that share my channel vector
+    float* mine = red + tid * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = a[j];
+        mine[4 + j] = b[j];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rlanes; ++k) {
+            const float* o = red + (tid + k * cv) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] += o[j];
+                b[j] += o[4 + j];
+            }
+        }
+        // one partial row per workgroup (same-address float atomics from ~2000 workgroups serialise at
+        // ~85 ns each -- measured 6x the streaming time of this kernel -- so a second small kernel sums them)
+        float* row = sums + (size_t)blockIdx.x * 2 * C;
+        *reinterpret_cast<f32x4*>(row + c) = a;
+        *reinterpret_cast<f32x4*>(row + C + c) = b;
+    }
+}
+
+// sums[j] += sum over the partial rows of a slice (gridDim.y slices -> gridDim.y atomics per address)
+__global__ __launch_bounds__(NT) void bn_bwd_sum_partials_kernel(const float* __restrict__ partials, float* __restrict__ sums,
+                                                                 int rows, int C2, int rows_per_slice) {
+    int j = blockIdx.x * NT + threadIdx.x;
+    if (j >= C2) return;
+    int r0 = blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        acc0 += partials[(size_t)r * C2 + j];
+        acc1 += partials[(size_t)(r + 1) * C2 + j];
+        acc2 += partials[(size_t)(r + 2) * C2 + j];
+        acc3 += partials[(size_t)(r + 3) * C2 + j];
+    }
+    for (; r < r1; ++r) acc0 += partials[(size_t)r * C2 + j];
+    if (r0 < r1) atomicAdd(sums + j, (acc0 + acc1) + (acc2 + acc3));
+}
+
+// dy = gamma * invstd * (du - sum_du / N - xhat * sum_du_xhat / N)
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ du, const float* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                          float* __restrict__ dy, size_t n4, int C, float inv_count) {
+    size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        int c = (int)((i * 4) % C);
+        f32x4 g = reinterpret_cast<const f32x4*>(du)[i], yy = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float xh = (yy[j] - mu[j]) * is[j];
+            o[j] = ga[j] * is[j] * (g[j] - s0[j] * inv_count - xh * s1[j] * inv_count);
+        }
+        reinterpret_cast<f32x4*>(dy)[i] = o;
+    }
+}
+
+inline unsigned stream_grid(size_t n4) {
+    size_t b = (n4 + NT - 1) / NT;
+    return (unsigned)(b > 2048 ? 2048 : (b == 0 ? 1 : b));     // 256 CUs x 8 blocks, grid-stride the rest
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                    float* invstd, int C, void* stream) {
+    DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1, "dvs_bn_finalize: bad argument");
+    DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_finalize: running stats come together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), stats,
+                       (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+    return dvs::check_launch("dvs_bn_finalize");
+}
+
+int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
+                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, void* stream) {
+    DVS_REQUIRE(y && scale && shift && z && M > 0 && C > 0 && (C & 3) == 0, "dvs_bn_apply_fwd: bad argument");
+    DVS_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual),
+                "dvs_bn_apply_fwd: residual affine needs residual, scale and shift");
+    size_t n4 = M * C / 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_BN_FWD, st);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(stream_grid(n4)), dim3(NT), 0, st, y, scale, shift, residual, res_scale,
+                       res_shift, z, n4, C, relu);
+    return dvs::check_launch("dvs_bn_apply_fwd");
+}
+
+namespace {
+inline void bn_reduce_geometry(size_t M, int C, int* blocks, int* rpb) {
+    const int rlanes = NT / (C / 4);
+    int r = (int)((M + 2047) / 2048);                 // at most 2048 workgroups ...
+    if (r < rlanes * 4) r = rlanes * 4;               // ... each with at least one unrolled pass per lane
+    *rpb = r;
+    *blocks = (int)((M + r - 1) / r);
+}
+}  // namespace
+
+size_t dvs_bn_bwd_workspace(size_t M, int C) {
+    if (M == 0 || C <= 0 || (C & 3) || C / 4 > NT || NT % (C / 4)) return 0;
+    int blocks, rpb;
+    bn_reduce_geometry(M, C, &blocks, &rpb);
+    return (size_t)blocks * 2 * C * sizeof(float);
+}
+
+int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                      float* du, float* sums, float* workspace, size_t M, int C, void* stream) {
+    DVS_REQUIRE(dz && y && mean && invstd && sums && workspace && M > 0 && C > 0 && (C & 3) == 0,
+                "dvs_bn_bwd_reduce: bad argument");
+    const int cv = C / 4;
+    DVS_REQUIRE(cv <= NT && (NT % cv) == 0, "dvs_bn_bwd_reduce: C/4 must divide 256 (C=%d)", C);
+    DVS_REQUIRE(M < 2147483648ull, "dvs_bn_bwd_reduce: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks, rpb;
+    bn_reduce_geometry(M, C, &blocks, &rpb);
+    {
+        dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
+                           invstd, du, workspace, (int)M, C, rpb);
+    }
+    const int slices = blocks >= 64 ? 32 : 1, rps = (blocks + slices - 1) / slices;
+    hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices), dim3(NT), 0, st, workspace, sums, blocks,
+                       2 * C, rps);
+    return dvs::check_launch("dvs_bn_bwd_reduce");
+}
+
+int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
+                     const float* sums, float* dy, size_t M, int C, void* stream) {
+    DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0, "dvs_bn_bwd_apply: bad argument");
+    size_t n4 = M * C / 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
+                       C, (float)(1.0 / (double)M));
+    return dvs::check_launch("dvs_bn_bwd_apply");
+}
+
+}  // extern "C"

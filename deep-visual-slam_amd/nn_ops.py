@@ -53,6 +53,28 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     return _ACT[act](F.conv2d(x, weight, bias, stride, padding))
 
 
+def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None):
+    """relu(bn(conv(x)) + residual') -- the conv -> BatchNorm2d -> (+identity) -> ReLU groups of torchvision's
+    BasicBlock / stem (model/resnet_encoder.py:100-111).  `residual` is the identity tensor; `res` =
+    (weight, bn, stride) describes the 1x1 downsample branch conv -> bn applied to `residual` instead.
+    HIP path: the conv epilogue accumulates the batch statistics, BN + add + ReLU is one fused pass."""
+    _require_gpu(x, "conv_bn_act")
+    from . import bn as _bn
+    planar = planar_norm is not None
+    fused = (conv_backend() == "hip" and _conv.supported(x, weight, None, planar) and _bn.supported_c(weight.shape[0], bn)
+             and (res is None or (_conv.supported(residual, res[0]) and _bn.supported_c(res[0].shape[0], res[1]))))
+    if fused:
+        y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=True)
+        if res is not None:
+            yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=True)
+            return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std)
+        return _bn.bn_act(y, bn, st, relu, residual=residual)
+    y = conv2d(x, weight, None, stride, padding, planar_norm=planar_norm)
+    if res is not None:
+        residual = batch_norm(conv2d(residual, res[0], None, res[2], 0), res[1])
+    return batch_norm(y, bn, relu=relu, residual=residual)
+
+
 def batch_norm(x, bn, relu=False, residual=None):
     """nn.BatchNorm2d forward (batch statistics + running-stat update in training mode), optionally
     followed by `+ residual` and ReLU: the BasicBlock tail."""

@@ -28,14 +28,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = nn_ops.conv2d(x, self.conv1.weight, None, self.stride, 1)
-        out = nn_ops.batch_norm(out, self.bn1, relu=True)
-        out = nn_ops.conv2d(out, self.conv2.weight, None, 1, 1)
-        identity = x
+        out = nn_ops.conv_bn_act(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
+        res = None
         if self.downsample is not None:
-            identity = nn_ops.conv2d(x, self.downsample[0].weight, None, self.stride, 0)
-            identity = nn_ops.batch_norm(identity, self.downsample[1])
-        return nn_ops.batch_norm(out, self.bn2, relu=True, residual=identity)
+            res = (self.downsample[0].weight, self.downsample[1], self.stride)
+        return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x, res=res)
 
 
 class ResNet(nn.Module):
@@ -116,8 +113,8 @@ class ResnetEncoder(nn.Module):
         nch = input_image.shape[1]
         scale = torch.full((nch,), 1.0 / 0.225, device=input_image.device)
         shift = torch.full((nch,), -0.45 / 0.225, device=input_image.device)
-        x = nn_ops.conv2d(input_image, e.conv1.weight, None, 2, 3, planar_norm=(scale, shift))
-        self.features.append(nn_ops.batch_norm(x, e.bn1, relu=True))
+        self.features.append(nn_ops.conv_bn_act(input_image, e.conv1.weight, e.bn1, 2, 3, relu=True,
+                                                planar_norm=(scale, shift)))
         x = nn_ops.max_pool_3x3_s2(self.features[-1])
         for layer in (e.layer1, e.layer2, e.layer3, e.layer4):
             for block in layer:

@@ -124,6 +124,31 @@ int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, c
                      const dvs_conv_fusion* f, const float* y_out, int dact, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1  training-mode BatchNorm2d (+ residual add, + ReLU) of the ResNet BasicBlocks on NHWC tensors
+ *     (torchvision BasicBlock tail used by model/resnet_encoder.py:100-111).  `stats` = [2][C] per-channel
+ *     sum / sum of squares of y as accumulated by dvs_conv2d_fwd's epilogue; count = B*H*W.
+ *       finalize : mean, invstd = rsqrt(biased var + eps); scale = gamma*invstd; shift = beta - mean*scale;
+ *                  running_mean/var updated with `momentum` (unbiased var), NULL = leave them.
+ *       apply_fwd: z = [relu](y*scale + shift [+ residual | + residual*res_scale + res_shift]).
+ *       bwd_reduce: du = dz * [z > 0] (z NULL = no ReLU; du NULL = do not store); sums[0][c] += sum du,
+ *                  sums[1][c] += sum du * xhat (= d beta, d gamma); caller zero-fills sums.
+ *       bwd_apply: dy = gamma * invstd * (du - sums0/M - xhat * sums1/M).
+ *     M = pixels (rows), C % 4 == 0 and C/4 divides 256 (C in {16..1024}).
+ * ------------------------------------------------------------------------------------------- */
+int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                    float* invstd, int C, void* stream);
+int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
+                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu,
+                     void* stream);
+/* bytes of the per-workgroup partial-sum workspace of dvs_bn_bwd_reduce (0 = unsupported shape) */
+size_t dvs_bn_bwd_workspace(size_t M, int C);
+int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                      float* du, float* sums, float* workspace, size_t M, int C, void* stream);
+int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
+                     const float* sums, float* dy, size_t M, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion
  *     replaces transformation_from_parameters / rot_from_axisangle / get_translation_matrix
  *     (vo/learner_func.py:29-104 == model/layers.py:28-103).

@@ -1,0 +1,57 @@
+"""Fused training-mode BatchNorm (+ residual, + ReLU) vs nn.BatchNorm2d + add + relu (forward values,
+running statistics, input / residual / affine gradients)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("C,H,W,mode", [(64, 24, 40, "plain"), (128, 12, 20, "residual"), (256, 7, 9, "res_bn"),
+                                         (512, 5, 6, "residual"), (64, 17, 23, "norelu")])
+def test_conv_bn_act(gpu_device, C, H, W, mode):
+    from deep_visual_slam_amd import nn_ops
+    torch.manual_seed(0)
+    B = 3
+    dev = gpu_device
+    cin = C // 2 if mode == "res_bn" else C
+    x = torch.randn(B, cin, H * (2 if mode == "res_bn" else 1), W * (2 if mode == "res_bn" else 1), device=dev)
+    x = x.contiguous(memory_format=CL).requires_grad_(True)
+    stride = 2 if mode == "res_bn" else 1
+    w = (torch.randn(C, cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=CL).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C).to(dev).train()
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.3, 0.3)
+    bn_ref = torch.nn.BatchNorm2d(C).to(dev).train(); bn_ref.load_state_dict(bn.state_dict())
+    relu = mode != "norelu"
+    res_in = res = res_ref = None
+    if mode == "residual":
+        res_in = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=CL).requires_grad_(True)
+    elif mode == "res_bn":
+        wd = (torch.randn(C, cin, 1, 1, device=dev) * 0.2).requires_grad_(True)
+        bnd = torch.nn.BatchNorm2d(C).to(dev).train(); bnd.weight.data.uniform_(0.5, 1.5)
+        bnd_ref = torch.nn.BatchNorm2d(C).to(dev).train(); bnd_ref.load_state_dict(bnd.state_dict())
+        res = (wd, bnd, 2)
+        res_in = x
+    # reference composition
+    y = bn_ref(F.conv2d(x, w, None, stride, 1))
+    if mode == "residual":
+        y = y + res_in
+    elif mode == "res_bn":
+        y = y + bnd_ref(F.conv2d(x, wd, None, 2, 0))
+    z_ref = F.relu(y) if relu else y
+    z = nn_ops.conv_bn_act(x, w, bn, stride, 1, relu=relu, residual=res_in, res=res)
+    assert rel(z, z_ref) < 5e-5
+    assert rel(bn.running_mean, bn_ref.running_mean) < 1e-4 and rel(bn.running_var, bn_ref.running_var) < 1e-4
+    assert int(bn.num_batches_tracked) == 1
+    cot = torch.randn_like(z_ref)
+    ins = [x, w, bn.weight, bn.bias] + ([res_in] if mode == "residual" else []) + ([wd, bnd.weight, bnd.bias] if mode == "res_bn" else [])
+    ins_ref = [x, w, bn_ref.weight, bn_ref.bias] + ([res_in] if mode == "residual" else []) + ([wd, bnd_ref.weight, bnd_ref.bias] if mode == "res_bn" else [])
+    g = torch.autograd.grad(z, ins, cot)
+    g_ref = torch.autograd.grad(z_ref, ins_ref, cot)
+    for a, r, i in zip(g, g_ref, range(len(g))):
+        assert rel(a, r) < 5e-4, (i, rel(a, r))
