@@ -6,7 +6,7 @@ and two backward (model/resnet_encoder.py:100-111 through torchvision's BasicBlo
 """
 import torch
 
-from . import _lib
+from . import _lib, zeropool
 from ._lib import check, ptr
 
 CL = torch.channels_last
@@ -55,7 +55,7 @@ class _BNAct(torch.autograd.Function):
         st = _lib.stream()
         need_du = ctx.relu or residual is not None
         du = torch.empty_like(y) if need_du else dz
-        sums = torch.zeros(2, C, device=y.device, dtype=torch.float32)
+        sums = zeropool.zeros((2, C), y.device, pooled=gamma.grad is not None)
         ws = torch.empty(l.dvs_bn_bwd_workspace(M, C) // 4, device=y.device, dtype=torch.float32)
         check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(), fin[2].data_ptr(),
                                   fin[3].data_ptr(), du.data_ptr() if need_du else None, ptr(sums), ptr(ws), M, C, st),
@@ -69,7 +69,7 @@ class _BNAct(torch.autograd.Function):
             if res_fin is None:
                 d_res = du
             else:
-                rsums = torch.zeros(2, C, device=y.device, dtype=torch.float32)
+                rsums = zeropool.zeros((2, C), y.device, pooled=gamma.grad is not None)
                 check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[2].data_ptr(),
                                           res_fin[3].data_ptr(), None, ptr(rsums), ptr(ws), M, C, st), "dvs_bn_bwd_reduce")
                 d_res = torch.empty_like(residual)

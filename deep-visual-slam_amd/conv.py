@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, zeropool
 from ._lib import ConvDesc, ConvFusion, check, ptr
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
@@ -99,8 +99,10 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
     return y
 
 
-def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None):
-    """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect)."""
+def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0):
+    """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
+    split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
+    (d coarse [B,C1,H/2,W/2] -- the 2x2-summed gradient of the upsampled operand, d skip [B,Cin-C1,H,W] or None)."""
     l = _lib.lib()
     dy = _nhwc(dy)
     w = _nhwc(weight)
@@ -109,16 +111,24 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
     wt = torch.empty(Cin * kh * kw * Cout, device=dy.device, dtype=torch.float32)
     check(l.dvs_conv2d_pack_wt(w.data_ptr(), wt.data_ptr(), Cout, Cin, kh, kw, _lib.stream()), "dvs_conv2d_pack_wt")
     d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
-    dx = torch.empty((B, Cin, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
-    check(l.dvs_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact, _lib.stream()),
+    if split_c1:
+        dx = zeropool.zeros((B, H // 2, W // 2, split_c1), dy.device).permute(0, 3, 1, 2)      # NHWC memory
+        dskip = (torch.empty((B, Cin - split_c1, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
+                 if split_c1 < Cin else None)
+        check(l.dvs_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact,
+                                 dskip.data_ptr() if dskip is not None else None, split_c1, _lib.stream()),
+              "dvs_conv2d_dgrad")
+        return dx, dskip
+    dx = torch.empty((B, Cin, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
+    check(l.dvs_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact, None, 0, _lib.stream()),
           "dvs_conv2d_dgrad")
     return dx
 
 
 def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=None, act=None, x2=None, in_scale=None,
-                 in_shift=None, in_relu=False, nchw_planar=False):
+                 in_shift=None, in_relu=False, nchw_planar=False, pooled=False):
     """(dW with the weight's logical shape, dbias or None)."""
     l = _lib.lib()
     dy = _nhwc(dy)
@@ -126,10 +136,10 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
     x, x2, B, Cin, H, W = _geometry(x, tuple(weight_shape), x2, nchw_planar)
     d = _desc(B, Cin, H, W, weight_shape, stride, pad, reflect)
     if nchw_planar:
-        dw = torch.zeros((Cout, Cin, kh, 8), device=dy.device, dtype=torch.float32)
+        dw = zeropool.zeros((Cout, Cin, kh, 8), dy.device, pooled=pooled)
     else:
-        dw = torch.zeros(tuple(weight_shape), device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
-    db = torch.zeros(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
+    db = zeropool.zeros((Cout,), dy.device, pooled=pooled) if want_bias else None
     f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar)
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
@@ -147,7 +157,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, x2, opts):
         stride, pad, reflect, act, planar, scale, shift, want_stats = opts
-        stats = torch.zeros(2, weight.shape[0], device=x.device, dtype=torch.float32) if want_stats else None
+        stats = zeropool.zeros((2, weight.shape[0]), x.device) if want_stats else None
         y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
                            nchw_planar=planar, stats=stats)
         ctx.opts = opts[:7]
@@ -176,15 +186,59 @@ class _Conv2d(torch.autograd.Function):
                 dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
             else:
                 C1, H, W = ctx.x_shape[1], 2 * ctx.x_shape[2], 2 * ctx.x_shape[3]
-                dcat = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act)
-                # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split
-                dx = torch.nn.functional.avg_pool2d(dcat[:, :C1], 2) * 4.0
-                if not ctx.up_only:
-                    dx2 = dcat[:, C1:].contiguous(memory_format=CL)
+                # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split: both done in
+                # the data-gradient kernel's epilogue
+                dx, dx2 = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act, split_c1=C1)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            # pool-backed scratch only when autograd will add it into an existing .grad (never adopt it)
             dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
-                                  in_scale=scale, in_shift=shift, nchw_planar=planar)
+                                  in_scale=scale, in_shift=shift, nchw_planar=planar, pooled=weight.grad is not None)
         return dx, dw, db, dx2, None
+
+
+class _HeadConv(torch.autograd.Function):
+    """Narrow-output convolution (Cout <= 8, stride 1, 'same' size) on the vector ALUs: the disparity heads
+    and PoseNet's last 1x1 (dvs_conv2d_head_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, reflect, act):
+        x, w = _nhwc(x), _nhwc(weight)
+        B, Cin, H, W = x.shape
+        d = _desc(B, Cin, H, W, weight.shape, 1, pad, reflect)
+        y = torch.empty((B, weight.shape[0], H, W), device=x.device, dtype=torch.float32, memory_format=CL)
+        check(_lib.lib().dvs_conv2d_head_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), ACT[act],
+                                             _lib.stream()), "dvs_conv2d_head_fwd")
+        ctx.cfg = (pad, reflect, act, bias is not None)
+        ctx.pooled = weight.grad is not None and (bias is None or bias.grad is not None)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        pad, reflect, act, has_bias = ctx.cfg
+        B, Cin, H, W = x.shape
+        d = _desc(B, Cin, H, W, w.shape, 1, pad, reflect)
+        dy = _nhwc(dy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
+        db = zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None
+        check(_lib.lib().dvs_conv2d_head_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(),
+                                             dx.data_ptr() if dx is not None else None, dw.data_ptr(), ptr(db), C.byref(d),
+                                             ACT[act], _lib.stream()), "dvs_conv2d_head_bwd")
+        return dx, dw, db, None, None, None
+
+
+def head_supported(x, weight, stride, padding, reflect_pad, x2=None, upsample=False, planar=False):
+    cout, cin, kh, kw = weight.shape
+    pad = reflect_pad if reflect_pad else padding
+    return (cout in (1, 2, 6, 8) and cin % 4 == 0 and stride == 1 and kh == kw and 2 * pad == kh - 1 and x2 is None
+            and not upsample and not planar and cout * kh * kw * cin * 4 <= 60 * 1024)
+
+
+def head_conv2d(x, weight, bias, padding, reflect_pad, act):
+    pad, reflect = (reflect_pad, True) if reflect_pad else (padding, False)
+    return _HeadConv.apply(x, weight, bias, pad, reflect, act)
 
 
 def supported(x, weight, x2=None, planar=False, upsample=False):

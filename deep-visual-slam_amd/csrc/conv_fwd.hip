@@ -25,6 +25,8 @@ struct FwdParams {
     const float* bias;   // [Cout] or NULL
     float* y;            // [B,Ho,Wo,Cout]
     float* stats;        // [2][Cout] running sum / sum of squares of the raw output, or NULL
+    float* y2;           // data gradient of an upsample+concat conv: channels >= split_c1 go here ([B,H,W,Cout-C1]) ...
+    int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
     ConvShape s;
     InXform t;
     int act;
@@ -219,7 +221,19 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
                         int oy = rem / Wr, ox = rem - oy * Wr;
                         pix = ((size_t)b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
                     }
-                    p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
+                    if (MODE == IN_DGRAD && p.split_c1 > 0) {
+                        // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
+                        if (n < p.split_c1) {
+                            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+                            int yy = rem / s.Wo, xx = rem - yy * s.Wo;
+                            size_t cp = ((size_t)b * (s.Ho >> 1) + (yy >> 1)) * (s.Wo >> 1) + (xx >> 1);
+                            atomicAdd(p.y + cp * p.split_c1 + n, v);
+                        } else {
+                            p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
+                        }
+                    } else {
+                        p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
+                    }
                 }
             }
         }
@@ -320,8 +334,11 @@ int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int
 }
 
 int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
-                     int dact, void* stream) {
+                     int dact, float* dx_skip, int C1, void* stream) {
     DVS_REQUIRE(dy && wt && dx && d, "dvs_conv2d_dgrad: null pointer");
+    DVS_REQUIRE(C1 == 0 || (d->stride == 1 && (d->H & 1) == 0 && (d->W & 1) == 0 && C1 <= d->Cin &&
+                            (C1 == d->Cin || dx_skip != nullptr)),
+                "dvs_conv2d_dgrad: bad upsample+concat split");
     DVS_REQUIRE(d->stride == 1 || d->stride == 2, "dvs_conv2d_dgrad: stride %d (1 or 2 supported)", d->stride);
     DVS_REQUIRE((d->Cout & 3) == 0 && (d->Cin & 3) == 0, "dvs_conv2d_dgrad: channel counts must be multiples of 4");
     DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 2 && d->W >= 2),
@@ -340,6 +357,8 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     s.Ktot = d->kh * d->kw * d->Cout;
     p.t.aux = y_out;
     p.t.dact = dact;
+    p.y2 = dx_skip;
+    p.split_c1 = C1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     launch_mode<IN_DGRAD, false>(p, st, dvs::SLOT_CONV_DGRAD);
     return dvs::check_launch("dvs_conv2d_dgrad");

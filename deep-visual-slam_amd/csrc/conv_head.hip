@@ -1,0 +1,287 @@
+// a2/a3: the narrow output heads -- DepthNet's four 3x3 "dispconv" layers (Cin 16..128 -> 1 channel, reflection
+// pad, sigmoid; model/depthnet.py:57-58,86-88) and PoseNet's final 1x1 (256 -> 6; model/posenet_single.py:165).
+//
+// With 1..8 output channels a 32-wide MFMA tile would idle 75-97 % of the matrix core and these layers are
+// pure bandwidth anyway (one pass over a [B,H,W,Cin] map), so they run on the vector ALUs:
+//   forward : one lane per output pixel, weights in LDS, 16-byte channel gathers (neighbouring lanes walk
+//             neighbouring pixels, so every cache line fetched is fully used by the wave);
+//   dgrad   : one lane per (pixel, 4 input channels);
+//   wgrad   : lanes own 4-wide k-slices, workgroups own pixel ranges, register accumulation, one atomic
+//             per (workgroup, weight) at the end.
+// Same NHWC layouts and [Cout][kh][kw][Cin] weights as the MFMA kernels (conv_common.h).
+#include "conv_common.h"
+
+namespace {
+using namespace dvsconv;
+
+constexpr int HNT = 256;
+constexpr int MAXCO = 8;
+
+struct HeadParams {
+    const float* x;      // [B,H,W,Cin]
+    const float* w;      // [Cout][kh][kw][Cin]
+    const float* bias;
+    float* y;            // [B,H,W,Cout]   (stride 1, "same" size)
+    const float* dy;     // backward: gradient of y (post-activation)
+    float* dx;           // [B,H,W,Cin]
+    float* dw;           // [Cout][Ktot], atomics
+    float* dbias;        // [Cout], atomics
+    int B, H, W, Cin, Cout, k, pad, reflect, act;
+    int pix_per_block;
+};
+
+__device__ __forceinline__ int src_index(int i, int n, int reflect, bool& ok) {
+    if (reflect) return reflect_i(i, n);
+    ok = ok && (unsigned)i < (unsigned)n;
+    return clampi(i, n);
+}
+
+template <int COUT, int KS>
+__global__ __launch_bounds__(HNT) void head_fwd_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];       // [COUT][Ktot]
+    const int Ktot = KS * KS * p.Cin, M = p.B * p.H * p.W;
+    for (int i = threadIdx.x; i < COUT * Ktot; i += HNT) sw[i] = p.w[i];
+    __syncthreads();
+    const int m = blockIdx.x * HNT + threadIdx.x;
+    if (m >= M) return;
+    const int b = m / (p.H * p.W), rem = m - b * (p.H * p.W), oy = rem / p.W, ox = rem - oy * p.W;
+    // the KS*KS source pixels of this output pixel (padding resolved once); all taps of a channel slice are
+    // loaded before any is consumed, so KS*KS independent 16-byte loads are in flight per lane
+    const float* src[KS * KS];
+    bool ok[KS * KS];
+#pragma unroll
+    for (int t = 0; t < KS * KS; ++t) {
+        bool v = true;
+        int iy = src_index(oy - p.pad + t / KS, p.H, p.reflect, v), ix = src_index(ox - p.pad + t % KS, p.W, p.reflect, v);
+        ok[t] = v;
+        src[t] = p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin;
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = p.bias ? p.bias[c] : 0.f;
+    for (int ci = 0; ci < p.Cin; ci += 4) {
+        f32x4 v[KS * KS];
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) v[t] = *reinterpret_cast<const f32x4*>(src[t] + ci);
+#pragma unroll
+        for (int t = 0; t < KS * KS; ++t) {
+            if (!ok[t]) continue;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                f32x4 wv = *reinterpret_cast<const f32x4*>(sw + c * Ktot + t * p.Cin + ci);
+                acc[c] = fmaf(v[t][0], wv[0], fmaf(v[t][1], wv[1], fmaf(v[t][2], wv[2], fmaf(v[t][3], wv[3], acc[c]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) p.y[(size_t)m * COUT + c] = apply_act(acc[c], p.act);
+}
+
+// dY' = dY * act'(Y) at pixel m, all COUT channels
+template <int COUT>
+__device__ __forceinline__ void load_dyp(const HeadParams& p, size_t m, float (&g)[COUT]) {
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        float v = p.dy[m * COUT + c];
+        if (p.act) v *= act_grad_from_out(p.y[m * COUT + c], p.act);
+        g[c] = v;
+    }
+}
+
+// dx[m][ci..ci+3] = sum_{tap,co} dY'[src(m,tap)][co] * w[co][tap][ci..]; reflection fold as in gather_dgrad_raw
+template <int COUT>
+__global__ __launch_bounds__(HNT) void head_dgrad_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];
+    const int Ktot = p.k * p.k * p.Cin, M = p.B * p.H * p.W, cv = p.Cin / 4;
+    for (int i = threadIdx.x; i < COUT * Ktot; i += HNT) sw[i] = p.w[i];
+    __syncthreads();
+    const size_t gid = (size_t)blockIdx.x * HNT + threadIdx.x;
+    if (gid >= (size_t)M * cv) return;
+    const int m = (int)(gid / cv), ci = (int)(gid % cv) * 4;
+    const int b = m / (p.H * p.W), rem = m - b * (p.H * p.W), y = rem / p.W, x = rem - y * p.W;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto add_from = [&](int ty, int tx, int ky, int kx) {
+        float g[COUT];
+        load_dyp<COUT>(p, ((size_t)b * p.H + ty) * p.W + tx, g);
+        const float* wp = sw + (ky * p.k + kx) * p.Cin + ci;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            f32x4 wv = *reinterpret_cast<const f32x4*>(wp + c * Ktot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(g[c], wv[j], acc[j]);
+        }
+    };
+    for (int ky = 0; ky < p.k; ++ky) {
+        for (int kx = 0; kx < p.k; ++kx) {
+            int ty = y + p.pad - ky, tx = x + p.pad - kx;
+            bool in_y = (unsigned)ty < (unsigned)p.H, in_x = (unsigned)tx < (unsigned)p.W;
+            if (in_y && in_x) add_from(ty, tx, ky, kx);
+            if (p.reflect) {
+                int ey = (y == 1 && ky == 0) ? 0 : ((y == p.H - 2 && ky == p.k - 1) ? p.H - 1 : -1);
+                int ex = (x == 1 && kx == 0) ? 0 : ((x == p.W - 2 && kx == p.k - 1) ? p.W - 1 : -1);
+                if (ey >= 0 && in_x) add_from(ey, tx, ky, kx);
+                if (ex >= 0 && in_y) add_from(ty, ex, ky, kx);
+                if (ey >= 0 && ex >= 0) add_from(ey, ex, ky, kx);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(p.dx + (size_t)m * p.Cin + ci) = acc;
+}
+
+// dW[co][k..k+3] += sum_pixels dY'[m][co] * x[src(m, tap(k))][ci(k)..]; lanes own k-slices, a workgroup owns a
+// pixel range; several pixel lanes per k-slice when Ktot/4 < 256.
+template <int COUT>
+__global__ __launch_bounds__(HNT) void head_wgrad_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];     // [HNT][COUT*4] for the pixel-lane reduction
+    const int Ktot = p.k * p.k * p.Cin, KV = Ktot / 4, M = p.B * p.H * p.W;
+    const int plane_count = max(1, HNT / KV);                        // pixel lanes per k-slice
+    const int kv_stride = (KV + HNT - 1) / HNT;                      // k-slices per lane when KV > 256
+    const int tid = threadIdx.x;
+    const int pl = (KV >= HNT) ? 0 : tid / KV, kv0 = (KV >= HNT) ? tid : tid % KV;
+    const bool lane_active = (KV >= HNT) || (pl < plane_count);
+    const int m0 = blockIdx.x * p.pix_per_block, m1 = min(M, m0 + p.pix_per_block);
+    float bsum[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) bsum[c] = 0.f;
+    for (int rep = 0; rep < kv_stride; ++rep) {
+        const int kv = kv0 + rep * HNT;
+        f32x4 acc[COUT];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane_active && kv < KV) {
+            const int k = kv * 4, tap = k / p.Cin, ci = k - tap * p.Cin, ky = tap / p.k, kx = tap - ky * p.k;
+            constexpr int U = 4;                                     // pixels in flight per lane
+            for (int mb = m0 + pl; mb < m1; mb += plane_count * U) {
+                f32x4 v[U];
+                float g[U][COUT];
+                bool okv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {                        // issue every load first
+                    int m = mb + u * plane_count;
+                    bool in = m < m1;
+                    m = min(m, m1 - 1);
+                    const int b = m / (p.H * p.W), rem = m - b * (p.H * p.W), oy = rem / p.W, ox = rem - oy * p.W;
+                    load_dyp<COUT>(p, (size_t)m, g[u]);
+                    bool ok = in;
+                    int iy = src_index(oy - p.pad + ky, p.H, p.reflect, ok), ix = src_index(ox - p.pad + kx, p.W, p.reflect, ok);
+                    okv[u] = ok;
+                    v[u] = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * p.H + iy) * p.W + ix) * p.Cin + ci);
+                    if (!in) {
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) g[u][c] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (rep == 0 && kv0 == 0) {
+#pragma unroll
+                        for (int c = 0; c < COUT; ++c) bsum[c] += g[u][c];
+                    }
+                    if (!okv[u]) continue;
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(g[u][c], v[u][j], acc[c][j]);
+                }
+            }
+        }
+        // reduce the pixel lanes of each k-slice through LDS, then one atomic per weight
+        if (KV < HNT) {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) *reinterpret_cast<f32x4*>(sred + (tid * COUT + c) * 4) = acc[c];
+            __syncthreads();
+            if (pl == 0 && kv < KV) {
+                for (int q = 1; q < plane_count; ++q)
+#pragma unroll
+                    for (int c = 0; c < COUT; ++c) acc[c] += *reinterpret_cast<const f32x4*>(sred + ((tid + q * KV) * COUT + c) * 4);
+            }
+        }
+        if (pl == 0 && kv < KV) {
+#pragma unroll
+            for (int c = 0; c < COUT; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(p.dw + (size_t)c * Ktot + kv * 4 + j, acc[c][j]);
+        }
+    }
+    if (p.dbias && kv0 == 0 && lane_active) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) atomicAdd(p.dbias + c, bsum[c]);
+    }
+}
+
+template <int COUT>
+int run(const HeadParams& p0, int op, hipStream_t st) {
+    HeadParams p = p0;
+    const int Ktot = p.k * p.k * p.Cin, M = p.B * p.H * p.W;
+    const size_t wbytes = (size_t)COUT * Ktot * sizeof(float);
+    if (op == 0) {
+        if (p.k == 3) hipLaunchKernelGGL((head_fwd_kernel<COUT, 3>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
+        else hipLaunchKernelGGL((head_fwd_kernel<COUT, 1>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
+    } else if (op == 1) {
+        size_t n = (size_t)M * (p.Cin / 4);
+        hipLaunchKernelGGL(head_dgrad_kernel<COUT>, dim3((unsigned)((n + HNT - 1) / HNT)), dim3(HNT), wbytes, st, p);
+    } else {
+        int blocks = (M + 511) / 512;
+        if (blocks > 512) blocks = 512;      // every workgroup ends with one atomic per weight: keep same-address traffic low
+        p.pix_per_block = (M + blocks - 1) / blocks;
+        blocks = (M + p.pix_per_block - 1) / p.pix_per_block;
+        hipLaunchKernelGGL(head_wgrad_kernel<COUT>, dim3(blocks), dim3(HNT), (size_t)HNT * COUT * 4 * sizeof(float), st, p);
+    }
+    return DVS_OK;
+}
+
+int dispatch(const HeadParams& p, int op, hipStream_t st) {
+    switch (p.Cout) {
+        case 1: return run<1>(p, op, st);
+        case 2: return run<2>(p, op, st);
+        case 6: return run<6>(p, op, st);
+        case 8: return run<8>(p, op, st);
+        default: return dvs::fail(DVS_ERR_UNSUPPORTED, "dvs_conv2d_head: Cout=%d (1, 2, 6, 8 supported)", p.Cout);
+    }
+}
+
+int fill(HeadParams& p, const dvs_conv_desc* d, int act, const char* who) {
+    DVS_REQUIRE(d, "%s: null descriptor", who);
+    DVS_REQUIRE(d->stride == 1 && d->kh == d->kw && 2 * d->pad == d->kh - 1 && (d->kh == 1 || d->kh == 3),
+                "%s: stride-1 'same' 1x1 / 3x3 convolutions only", who);
+    DVS_REQUIRE((d->Cin & 3) == 0 && d->Cout <= MAXCO, "%s: Cin %% 4 == 0 and Cout <= %d", who, MAXCO);
+    DVS_REQUIRE((size_t)d->Cout * d->kh * d->kw * d->Cin * 4 <= 60 * 1024, "%s: weights must fit 60 KB of LDS", who);
+    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->H >= 2 && d->W >= 2), "%s: reflection needs H, W >= 2", who);
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.k = d->kh; p.pad = d->pad;
+    p.reflect = d->pad_mode == PAD_REFLECT; p.act = act;
+    return DVS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_conv2d_head_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d, int act,
+                        void* stream) {
+    DVS_REQUIRE(x && w && y, "dvs_conv2d_head_fwd: null pointer");
+    HeadParams p{};
+    int rc = fill(p, d, act, "dvs_conv2d_head_fwd");
+    if (rc) return rc;
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    rc = dispatch(p, 0, static_cast<hipStream_t>(stream));
+    return rc ? rc : dvs::check_launch("dvs_conv2d_head_fwd");
+}
+
+int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                        float* dbias, const dvs_conv_desc* d, int act, void* stream) {
+    DVS_REQUIRE(x && w && y && dy && dw, "dvs_conv2d_head_bwd: null pointer");
+    HeadParams p{};
+    int rc = fill(p, d, act, "dvs_conv2d_head_bwd");
+    if (rc) return rc;
+    p.x = x; p.w = w; p.y = const_cast<float*>(y); p.dy = dy; p.dx = dx; p.dw = dw; p.dbias = dbias;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dx) {
+        rc = dispatch(p, 1, st);
+        if (rc) return rc;
+    }
+    rc = dispatch(p, 2, st);
+    return rc ? rc : dvs::check_launch("dvs_conv2d_head_bwd");
+}
+
+}  // extern "C"

@@ -13,7 +13,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, zeropool
 from .layers import SSIM, BackprojectDepth, Project3D
 
 
@@ -77,6 +77,7 @@ class MonodepthTrainer:
         for key in sample:
             if isinstance(sample[key], torch.Tensor):
                 sample[key] = sample[key].to(self.device, non_blocking=True)
+        zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
         outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
         outputs.update(self._predict_poses(sample))
         losses = self._fused_losses(sample, outputs)

@@ -37,9 +37,12 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     with (x - 0.45) / 0.225 folded in (model/resnet_encoder.py:102-103)."""
     _require_gpu(x, "conv2d")
     planar = planar_norm is not None
-    if conv_backend() == "hip" and _conv.supported(x, weight, x2, planar, upsample):
-        return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
-                            planar_norm=planar_norm)
+    if conv_backend() == "hip":
+        if _conv.supported(x, weight, x2, planar, upsample):
+            return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
+                                planar_norm=planar_norm)
+        if _conv.head_supported(x, weight, stride, padding, reflect_pad, x2, upsample, planar):
+            return _conv.head_conv2d(x, weight, bias, padding, reflect_pad, act)
     # library path (also serves the 1- and 6-channel heads)
     if planar:
         sc, sh = planar_norm

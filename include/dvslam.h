@@ -118,10 +118,22 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *                       nchw_planar; act/stats ignored).  With nchw_planar dw is packed [Cout][Cin][kh][8].
  *   Channel counts must be multiples of 4 (NHWC 16-byte gathers). */
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
+/*   dx_skip / C1 (upsample+concat forward only, else NULL / 0): the gradient is split in the epilogue --
+ *   channels [0,C1) are summed over each 2x2 block into dx = [B,H/2,W/2,C1] with atomics (caller zero-fills dx),
+ *   channels [C1,Cin) are stored to dx_skip = [B,H,W,Cin-C1]; C1 == Cin (upsample only) needs no dx_skip. */
 int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
-                     int dact, void* stream);
+                     int dact, float* dx_skip, int C1, void* stream);
 int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
                      const dvs_conv_fusion* f, const float* y_out, int dact, void* stream);
+
+/* Narrow output heads (Cout in {1,2,6,8}, Cin % 4 == 0, stride 1, "same" size: 2*pad == k-1) on the vector
+ * ALUs: DepthNet's dispconv layers (model/depthnet.py:57-58,86-88) and PoseNet's last 1x1
+ * (model/posenet_single.py:165).  `act` as in dvs_conv_fusion.  bwd: dx (NULL = skip), dw/dbias accumulated
+ * with atomics (caller zero-fills); y / dy are the forward output and its gradient. */
+int dvs_conv2d_head_fwd(const float* x, const float* w, const float* bias, float* y, const dvs_conv_desc* d, int act,
+                        void* stream);
+int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                        float* dbias, const dvs_conv_desc* d, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1  training-mode BatchNorm2d (+ residual add, + ReLU) of the ResNet BasicBlocks on NHWC tensors

@@ -115,3 +115,25 @@ def test_unsupported_shapes_are_reported(gpu_device):
     assert not DC.supported(x, torch.zeros(1, 16, 3, 3))       # 1-channel disparity head
     assert not DC.supported(x, torch.zeros(6, 256, 1, 1))      # 6-channel pose head
     assert DC.supported(x, torch.zeros(16, 16, 3, 3))
+
+
+@pytest.mark.parametrize("cin,cout,k,refl,act,H,W", [(16, 1, 3, True, "sigmoid", 40, 56), (128, 1, 3, True, "sigmoid", 9, 13),
+                                                    (256, 6, 1, False, None, 7, 9), (32, 1, 3, True, "sigmoid", 3, 4)])
+def test_head_conv(gpu_device, cin, cout, k, refl, act, H, W):
+    """Disparity heads (reflect-pad 3x3 -> 1 channel -> sigmoid) and PoseNet's 1x1 -> 6 channels."""
+    from deep_visual_slam_amd import nn_ops
+    torch.manual_seed(4)
+    B = 2
+    x = torch.randn(B, cin, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k, device=gpu_device) * 0.1).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(cout, device=gpu_device) * 0.1).requires_grad_(True)
+    p = (k - 1) // 2
+    xx = F.pad(x, (p,) * 4, mode="reflect") if refl else x
+    y_ref = ref_act(F.conv2d(xx, w, b, 1, 0 if refl else p), act)
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [x, w, b], cot)
+    y = nn_ops.conv2d(x, w, b, 1, 0 if refl else p, reflect_pad=p if refl else 0, act=act)
+    assert y.shape == y_ref.shape and relmax(y, y_ref) < 2e-5
+    g = torch.autograd.grad(y, [x, w, b], cot)
+    for a, r, nm in zip(g, g_ref, ("dx", "dw", "db")):
+        assert a.shape == r.shape and relmax(a, r) < 1e-4, (nm, relmax(a, r))
