@@ -27,10 +27,69 @@ struct FwdParams {
     float* stats;        // [2][Cout] running sum / sum of squares of the raw output, or NULL
     float* y2;           // data gradient of an upsample+concat conv: channels >= split_c1 go here ([B,H,W,Cout-C1]) ...
     int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
+    int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
     ConvShape s;
     InXform t;
     int act;
 };
+
+// Epilogue shared by the register-staged and the LDS-DMA kernels: bias, activation, BatchNorm statistics,
+// the data-gradient row mappings (stride-2 parity classes, upsample+concat split) and the NHWC store.
+template <int TM, int TN, int MODE>
+__device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int lane, int M, int Hr, int Wr, int rstep, int oy0, int ox0) {
+    // epilogue.  C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = n0 + (wn * TN + tn) * 32 + ln;
+        const bool n_ok = n < s.Cout;
+        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int m = mb + (i & 3) + 8 * (i >> 2);
+                float v = acc[tm][tn][i];
+                if (m < M && n_ok) {
+                    ssum += v;
+                    ssq += v * v;
+                    size_t pix = (size_t)m;
+                    if (MODE == IN_DGRAD && rstep == 2) {       // parity-class row -> pixel of the full grid
+                        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
+                        int oy = rem / Wr, ox = rem - oy * Wr;
+                        pix = ((size_t)b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
+                    }
+                    if (MODE == IN_DGRAD && p.split_c1 > 0) {
+                        // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
+                        if (n < p.split_c1) {
+                            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+                            int yy = rem / s.Wo, xx = rem - yy * s.Wo;
+                            size_t cp = ((size_t)b * (s.Ho >> 1) + (yy >> 1)) * (s.Wo >> 1) + (xx >> 1);
+                            atomicAdd(p.y + cp * p.split_c1 + n, v);
+                        } else {
+                            p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
+                        }
+                    } else {
+                        p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
+                    }
+                }
+            }
+        }
+        if (p.stats) {
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (lh == 0 && n_ok) {
+                atomicAdd(p.stats + n, ssum);
+                atomicAdd(p.stats + s.Cout + n, ssq);
+            }
+        }
+    }
+}
+
+#include "conv_dma.h"
 
 // NBUF = 2: double-buffered LDS, one barrier per K-step (2 workgroups / CU for the 128-wide tiles);
 // NBUF = 1: one LDS buffer, the next stage waits in registers, two barriers per K-step but half the LDS,
@@ -123,6 +182,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
                 if (MODE == IN_DGRAD) dgrad_tap_setup(p.s, a_b[j], a_iy[j], a_ix[j], ky, kx, ok, t_off[j]);
                 else tap_setup<MODE>(s, p.t, a_b[j], a_iy[j] + kp.ky, a_ix[j] + kp.kx, ok, t_off[j], t_off2[j]);
                 t_ok[j] = ok;
+                if (p.dbg_nobarrier & 2) t_off[j] = t_off2[j] = 0;      // experiment: every row gathers pixel 0 (cache-resident)
             }
         }
 #pragma unroll
@@ -190,62 +250,15 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = (NBUF == 2) ? (kt & 1) : 0;
-        if (kt + 1 < KT) load_stage();                // global loads in flight during the MFMAs
+        const bool staged = !(p.dbg_nobarrier & 4);   // experiment bit 4: MFMA + LDS reads only
+        if (staged && kt + 1 < KT) load_stage();      // global loads in flight during the MFMAs
         mfma_stage<TM, TN>(As + buf * BM * LDK, Bs + buf * BN * LDK, wm * TM * 32, wn * TN * 32, lane, acc);
-        if (NBUF == 1) __syncthreads();               // everyone is done reading the single buffer
-        if (kt + 1 < KT) store_stage((NBUF == 2) ? (buf ^ 1) : 0);
-        __syncthreads();
+        if (NBUF == 1 && !(p.dbg_nobarrier & 1)) __syncthreads();   // everyone is done reading the single buffer
+        if (staged && kt + 1 < KT) store_stage((NBUF == 2) ? (buf ^ 1) : 0);
+        if (!(p.dbg_nobarrier & 1)) __syncthreads();
     }
 
-    // epilogue.  C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int ln = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = n0 + (wn * TN + tn) * 32 + ln;
-        const bool n_ok = n < s.Cout;
-        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
-        float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int m = mb + (i & 3) + 8 * (i >> 2);
-                float v = acc[tm][tn][i];
-                if (m < M && n_ok) {
-                    ssum += v;
-                    ssq += v * v;
-                    size_t pix = (size_t)m;
-                    if (MODE == IN_DGRAD && rstep == 2) {       // parity-class row -> pixel of the full grid
-                        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
-                        int oy = rem / Wr, ox = rem - oy * Wr;
-                        pix = ((size_t)b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
-                    }
-                    if (MODE == IN_DGRAD && p.split_c1 > 0) {
-                        // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
-                        if (n < p.split_c1) {
-                            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
-                            int yy = rem / s.Wo, xx = rem - yy * s.Wo;
-                            size_t cp = ((size_t)b * (s.Ho >> 1) + (yy >> 1)) * (s.Wo >> 1) + (xx >> 1);
-                            atomicAdd(p.y + cp * p.split_c1 + n, v);
-                        } else {
-                            p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
-                        }
-                    } else {
-                        p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
-                    }
-                }
-            }
-        }
-        if (p.stats) {
-            ssum += __shfl_xor(ssum, 32, 64);
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (lh == 0 && n_ok) {
-                atomicAdd(p.stats + n, ssum);
-                atomicAdd(p.stats + s.Cout + n, ssq);
-            }
-        }
-    }
+    conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0);
 }
 
 int conv_nbuf() {
@@ -259,8 +272,48 @@ int conv_nbuf() {
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
 void launch_buf(const FwdParams& p, hipStream_t st, int slot);
 
+// LDS-DMA kernel (conv_dma.h) whenever the gather needs no per-element arithmetic and a 32-k stage stays
+// inside one tap; DVS_CONV_DMA=0 forces the register-staged kernel.
+template <int MODE, bool FOLD>
+bool dma_eligible(const FwdParams& p) {
+    static const bool enabled = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
+    if (!enabled || FOLD || MODE == IN_PLANAR || (p.s.Cin % BK) != 0) return false;
+    if (MODE == IN_DGRAD) return p.t.dact == 0 && p.s.pad_mode == PAD_ZERO && p.split_c1 == 0;
+    return true;
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
+    int M = p.s.B * p.s.Ho * p.s.Wo;
+    dim3 grid((M + BM - 1) / BM, (p.s.Cout + BN - 1) / BN);
+    if (MODE == IN_DGRAD && p.s.stride == 2) {
+        int mc = p.s.B * ((p.s.Ho + 1) / 2) * ((p.s.Wo + 1) / 2);
+        grid = dim3((mc + BM - 1) / BM, (p.s.Cout + BN - 1) / BN, 4);
+    }
+    size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    auto kern = conv_dma_kernel<BM, BN, WM, WN, MODE>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024 - 256) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dvs::ProfScope prof(slot, st);
+    const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;
+    prof.work(2.0 * M * p.s.Cout * (double)p.s.Ktot * eff);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
-void launch_cfg(const FwdParams& p, hipStream_t st, int slot) {
+void launch_cfg(const FwdParams& p0, hipStream_t st, int slot) {
+    FwdParams p = p0;
+    if constexpr (!FOLD && MODE != IN_PLANAR) {
+        if (dma_eligible<MODE, FOLD>(p)) {
+            launch_dma<BM, BN, WM, WN, MODE>(p, st, slot);
+            return;
+        }
+    }
+    static const int nobar = getenv("DVS_CONV_DEBUG_NOBARRIER") ? atoi(getenv("DVS_CONV_DEBUG_NOBARRIER")) : 0;
+    p.dbg_nobarrier = nobar;
     if (conv_nbuf() == 2) launch_buf<BM, BN, WM, WN, MODE, FOLD, 2>(p, st, slot);
     else launch_buf<BM, BN, WM, WN, MODE, FOLD, 1>(p, st, slot);
 }
@@ -292,12 +345,15 @@ template <int MODE, bool FOLD>
 void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
     const ConvShape& s = p.s;
     const int M = s.B * s.Ho * s.Wo;
+    // DVS_CONV_TILE=small: 64-row tiles everywhere (more, lighter workgroups; tuning experiments)
+    static const bool small = [] { const char* e = getenv("DVS_CONV_TILE"); return e && e[0] == 's'; }();
     if (s.Cout > 64) {
         // few output pixels (layer3/4, pose decoder): halve the M tile so the grid still covers the 256 CUs
-        if (((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
+        if (small || ((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
         else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, slot);
     } else if (s.Cout > 32) {
-        launch_cfg<128, 64, 2, 2, MODE, FOLD>(p, st, slot);
+        if (small) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
+        else launch_cfg<128, 64, 2, 2, MODE, FOLD>(p, st, slot);
     } else {
         launch_cfg<128, 32, 4, 1, MODE, FOLD>(p, st, slot);
     }
