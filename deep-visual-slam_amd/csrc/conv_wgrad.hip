@@ -13,6 +13,8 @@
 // Replaces the weight/bias gradient of nn.Conv2d (autograd of the modules cited in conv_fwd.hip).
 #include "conv_common.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace dvsconv;
 
@@ -187,6 +189,118 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
+// LDS-DMA variant (plain NHWC / upsample+concat input, no BatchNorm fold, no activation derivative, no bias):
+// the [pixel][channel] tiles are filled by `global_load_lds_dwordx4` (1 KB = 256 consecutive floats of a tile per
+// instruction, padding / tails served from a 16-byte zero page), so a stage costs no VGPR staging, no padding
+// selects and no ds_write pass.  Operand fetch is the same conflict-free ds_read_b32 as above (lanes run along
+// the channel dimension), hence no swizzle is needed here.
+__device__ __attribute__((aligned(16))) float g_dvs_zero_page_w[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int D_INS = BM / 32, X_INS = BN / 32;          // DMA instructions per wave per stage
+    constexpr int DV = BM / 4, XV = BN / 4;                  // 16-byte slots per pixel row
+    constexpr int D_RPI = 64 / DV, X_RPI = 64 / XV;          // pixel rows per instruction
+    static_assert(WM * WN == 4 && DV <= 64 && XV <= 64, "tile");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+
+    const ConvShape& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = s.B * s.Ho * s.Wo;
+    const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
+    const int m_begin = blockIdx.z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
+
+    const int d_c = (lane % DV) * 4, d_r = lane / DV;       // my channel slice / pixel row inside an instruction
+    const int co = co0 + d_c;
+    const bool co_ok = co < s.Cout;
+    const int x_c = (lane % XV) * 4, x_r = lane / XV;
+    const int k = k0 + x_c;
+    const bool k_ok = k < s.Ktot;
+    const int kc = min(k, s.Ktot - 4), tap = kc / s.Cin, ci = kc - tap * s.Cin, ky = tap / s.kw, kx = tap - ky * s.kw;
+
+    auto issue_stage = [&](int mb, int buf) {
+#pragma unroll
+        for (int j = 0; j < D_INS; ++j) {
+            const int row = (wave * D_INS + j) * D_RPI + d_r, m = mb + row;
+            const float* gp = p.dy + (size_t)min(m, M - 1) * s.Cout + min(co, s.Cout - 4);
+            if (!(m < m_end && co_ok)) gp = g_dvs_zero_page_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)&Ds[buf][(wave * D_INS + j) * D_RPI][0],
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < X_INS; ++j) {
+            const int row = (wave * X_INS + j) * X_RPI + x_r;
+            int m = mb + row;
+            bool ok = m < m_end && k_ok;
+            m = min(m, M - 1);
+            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+            int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+            int off, off2;
+            tap_setup<MODE>(s, p.t, b, oy * s.stride - s.pad + ky, ox * s.stride - s.pad + kx, ok, off, off2);
+            const float* gp;
+            if (MODE == IN_UPCAT && ci >= p.t.C1) gp = p.t.x2 + (off2 + ci);
+            else gp = p.x + (off + ci);
+            if (!ok) gp = g_dvs_zero_page_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                             (__attribute__((address_space(3))) void*)&Xs[buf][(wave * X_INS + j) * X_RPI][0],
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    const int a_col = wm * TM * 32 + r, b_col = wn * TN * 32 + r;
+    if (m_begin < m_end) issue_stage(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int mb = m_begin; mb < m_end; mb += BP) {
+        if (mb + BP < m_end) issue_stage(mb + BP, buf ^ 1);
+#pragma unroll
+        for (int t = 0; t < BP / 2; ++t) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = Ds[buf][2 * t + h][a_col + m * 32];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = Xs[buf][2 * t + h][b_col + n * 32];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int kk = k0 + (wn * TN + tn) * 32 + r;
+        if (kk >= s.Ktot) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int c = cb + (i & 3) + 8 * (i >> 2);
+                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(WgradParams p, hipStream_t st) {
     const int M = p.s.B * p.s.Ho * p.s.Wo;
@@ -200,6 +314,13 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     prof.work(2.0 * M * p.s.Cout * k_real);
+    if constexpr (!FOLD && MODE != IN_PLANAR) {
+        static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
+        if (dma && p.t.dact == 0 && p.dbias == nullptr) {
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), grid, dim3(NT), 0, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD>), grid, dim3(NT), 0, st, p);
 }
 
