@@ -28,6 +28,7 @@ struct WgradParams {
     ConvShape s;
     InXform t;           // forward input transform + (aux = Y, dact) for the dY side
     int m_per_split;     // pixels per blockIdx.z, multiple of BP
+    int dbg;             // timing experiment (DVS_CONV_DEBUG_NOBARRIER & 4): MFMA + LDS reads only -> wrong results
 };
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
@@ -221,6 +222,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     const bool k_ok = k < s.Ktot;
     const int kc = min(k, s.Ktot - 4), tap = kc / s.Cin, ci = kc - tap * s.Cin, ky = tap / s.kw, kx = tap - ky * s.kw;
 
+    // pixel coordinates of my X rows, advanced incrementally by BP pixels per stage (no divisions in the loop)
+    int x_b[X_INS], x_oy[X_INS], x_ox[X_INS];
+#pragma unroll
+    for (int j = 0; j < X_INS; ++j) {
+        int m = min(m_begin + (wave * X_INS + j) * X_RPI + x_r, M - 1);
+        x_b[j] = m / (s.Ho * s.Wo);
+        int rem = m - x_b[j] * (s.Ho * s.Wo);
+        x_oy[j] = rem / s.Wo;
+        x_ox[j] = rem - x_oy[j] * s.Wo;
+    }
     auto issue_stage = [&](int mb, int buf) {
 #pragma unroll
         for (int j = 0; j < D_INS; ++j) {
@@ -234,13 +245,20 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
 #pragma unroll
         for (int j = 0; j < X_INS; ++j) {
             const int row = (wave * X_INS + j) * X_RPI + x_r;
-            int m = mb + row;
+            const int m = mb + row;
             bool ok = m < m_end && k_ok;
-            m = min(m, M - 1);
-            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
-            int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+            const int b = min(x_b[j], s.B - 1), oy = x_oy[j], ox = x_ox[j];
             int off, off2;
             tap_setup<MODE>(s, p.t, b, oy * s.stride - s.pad + ky, ox * s.stride - s.pad + kx, ok, off, off2);
+            // next stage: BP pixels further along the flattened (b, oy, ox) index
+            x_ox[j] += BP;
+            while (x_ox[j] >= s.Wo) {
+                x_ox[j] -= s.Wo;
+                if (++x_oy[j] == s.Ho) {
+                    x_oy[j] = 0;
+                    ++x_b[j];
+                }
+            }
             const float* gp;
             if (MODE == IN_UPCAT && ci >= p.t.C1) gp = p.t.x2 + (off2 + ci);
             else gp = p.x + (off + ci);
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     int buf = 0;
 #pragma unroll 1
     for (int mb = m_begin; mb < m_end; mb += BP) {
-        if (mb + BP < m_end) issue_stage(mb + BP, buf ^ 1);
+        if (!p.dbg && mb + BP < m_end) issue_stage(mb + BP, buf ^ 1);
 #pragma unroll
         for (int t = 0; t < BP / 2; ++t) {
             float a[TM], b[TN];
@@ -316,6 +334,8 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     prof.work(2.0 * M * p.s.Cout * k_real);
     if constexpr (!FOLD && MODE != IN_PLANAR) {
         static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
+        static const int dbg = getenv("DVS_CONV_DEBUG_NOBARRIER") ? atoi(getenv("DVS_CONV_DEBUG_NOBARRIER")) : 0;
+        p.dbg = dbg & 4;
         if (dma && p.t.dact == 0 && p.dbias == nullptr) {
             hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), grid, dim3(NT), 0, st, p);
             return;
