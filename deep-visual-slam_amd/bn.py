@@ -6,7 +6,7 @@ and two backward (model/resnet_encoder.py:100-111 through torchvision's BasicBlo
 """
 import torch
 
-from . import _lib, zeropool
+from . import _lib, gradsink, zeropool
 from ._lib import check, ptr
 
 CL = torch.channels_last
@@ -17,14 +17,15 @@ def _finalize(stats, count, bn):
     dev = stats.device
     out = torch.empty(4, C, device=dev, dtype=torch.float32)      # scale, shift, mean, invstd
     train_stats = bn.training and bn.track_running_stats
+    nbt = bn.num_batches_tracked if train_stats else None
+    if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+        raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
     check(_lib.lib().dvs_bn_finalize(ptr(stats), float(count), ptr(bn.weight), ptr(bn.bias),
                                      ptr(bn.running_mean) if train_stats else None,
                                      ptr(bn.running_var) if train_stats else None,
                                      float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps),
                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), C,
-                                     _lib.stream()), "dvs_bn_finalize")
-    if train_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+                                     nbt.data_ptr() if nbt is not None else None, _lib.stream()), "dvs_bn_finalize")
     return out
 
 
@@ -42,6 +43,11 @@ class _BNAct(torch.autograd.Function):
                                  residual.data_ptr() if residual is not None else None, r_sc, r_sh, z.data_ptr(), M, C,
                                  int(relu), _lib.stream()), "dvs_bn_apply_fwd")
         ctx.relu = relu
+        ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
+        if ctx.needs_input_grad[1]:
+            gradsink.begin(gamma, beta)
+            if res_fin is not None:
+                gradsink.begin(res_gamma, res_beta)
         ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
         return z
 
@@ -61,9 +67,17 @@ class _BNAct(torch.autograd.Function):
                                   fin[3].data_ptr(), du.data_ptr() if need_du else None, ptr(sums), ptr(ws), M, C, st),
               "dvs_bn_bwd_reduce")
         dy = torch.empty_like(y)
+        g_par, b_par, rg_par, rb_par = ctx.affine
+        gs, bs = gradsink.target(g_par), gradsink.target(b_par)
+        sunk = gs is not None and bs is not None
         check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[2].data_ptr(), fin[3].data_ptr(), ptr(gamma), ptr(sums),
-                                 dy.data_ptr(), M, C, st), "dvs_bn_bwd_apply")
-        d_gamma, d_beta = sums[1], sums[0]
+                                 dy.data_ptr(), M, C, ptr(gs) if sunk else None, ptr(bs) if sunk else None, st),
+              "dvs_bn_bwd_apply")
+        if sunk:
+            d_gamma = d_beta = None
+            gradsink.done(g_par, b_par)
+        else:
+            d_gamma, d_beta = sums[1], sums[0]
         d_res = d_rg = d_rb = None
         if residual is not None:
             if res_fin is None:
@@ -73,9 +87,15 @@ class _BNAct(torch.autograd.Function):
                 check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[2].data_ptr(),
                                           res_fin[3].data_ptr(), None, ptr(rsums), ptr(ws), M, C, st), "dvs_bn_bwd_reduce")
                 d_res = torch.empty_like(residual)
+                gs, bs = gradsink.target(rg_par), gradsink.target(rb_par)
+                sunk = gs is not None and bs is not None
                 check(l.dvs_bn_bwd_apply(du.data_ptr(), residual.data_ptr(), res_fin[2].data_ptr(), res_fin[3].data_ptr(),
-                                         ptr(res_gamma), ptr(rsums), d_res.data_ptr(), M, C, st), "dvs_bn_bwd_apply")
-                d_rg, d_rb = rsums[1], rsums[0]
+                                         ptr(res_gamma), ptr(rsums), d_res.data_ptr(), M, C, ptr(gs) if sunk else None,
+                                         ptr(bs) if sunk else None, st), "dvs_bn_bwd_apply")
+                if sunk:
+                    gradsink.done(rg_par, rb_par)
+                else:
+                    d_rg, d_rb = rsums[1], rsums[0]
         return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None
 
 

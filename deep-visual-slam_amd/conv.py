@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib, zeropool
+from . import _lib, gradsink, zeropool
 from ._lib import ConvDesc, ConvFusion, check, ptr
 
 ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
@@ -128,18 +128,26 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
 
 
 def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=None, act=None, x2=None, in_scale=None,
-                 in_shift=None, in_relu=False, nchw_planar=False, pooled=False):
-    """(dW with the weight's logical shape, dbias or None)."""
+                 in_shift=None, in_relu=False, nchw_planar=False, pooled=False, dw_out=None, db_out=None):
+    """(dW with the weight's logical shape, dbias or None).  dw_out / db_out: gradient sinks (gradsink.py) --
+    accumulate into these instead of fresh zero-filled tensors; the corresponding result is None."""
     l = _lib.lib()
     dy = _nhwc(dy)
     Cout, _, kh, kw = weight_shape
     x, x2, B, Cin, H, W = _geometry(x, tuple(weight_shape), x2, nchw_planar)
     d = _desc(B, Cin, H, W, weight_shape, stride, pad, reflect)
-    if nchw_planar:
+    if dw_out is not None:
+        if nchw_planar or tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
+            raise _lib.DvsError("conv2d_wgrad: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
+        dw = dw_out
+    elif nchw_planar:
         dw = zeropool.zeros((Cout, Cin, kh, 8), dy.device, pooled=pooled)
     else:
         dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
-    db = zeropool.zeros((Cout,), dy.device, pooled=pooled) if want_bias else None
+    if db_out is not None:
+        db = db_out
+    else:
+        db = zeropool.zeros((Cout,), dy.device, pooled=pooled) if want_bias else None
     f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar)
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
@@ -147,7 +155,7 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
                              _lib.stream()), "dvs_conv2d_wgrad")
     if nchw_planar:
         dw = dw[..., :kw]
-    return dw, db
+    return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -157,12 +165,16 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, x2, opts):
         stride, pad, reflect, act, planar, scale, shift, want_stats = opts
+        ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
         stats = zeropool.zeros((2, weight.shape[0]), x.device) if want_stats else None
         y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
                            nchw_planar=planar, stats=stats)
         ctx.opts = opts[:7]
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias                      # only to find its gradient sink in backward
+        if ctx.needs_input_grad[1] and not planar:
+            gradsink.begin(weight, bias)
         ctx.up_only = x2 is UPSAMPLE_ONLY
         ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
         if want_stats:
@@ -175,6 +187,8 @@ class _Conv2d(torch.autograd.Function):
         x, weight, x2, y = ctx.saved_tensors
         stride, pad, reflect, act, planar, scale, shift = ctx.opts
         dx = dx2 = dw = db = None
+        if dy is None:
+            return None, None, None, None, None
         if ctx.up_only:
             x2 = UPSAMPLE_ONLY
         need_x = ctx.needs_input_grad[0] or (isinstance(x2, torch.Tensor) and ctx.needs_input_grad[3])
@@ -191,8 +205,15 @@ class _Conv2d(torch.autograd.Function):
                 dx, dx2 = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act, split_c1=C1)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # pool-backed scratch only when autograd will add it into an existing .grad (never adopt it)
+            wsink = None if planar else gradsink.target(weight)
+            bsink = None if planar else gradsink.target(ctx.bias_ref)
             dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
-                                  in_scale=scale, in_shift=shift, nchw_planar=planar, pooled=weight.grad is not None)
+                                  in_scale=scale, in_shift=shift, nchw_planar=planar, pooled=weight.grad is not None,
+                                  dw_out=wsink, db_out=bsink)
+            if wsink is not None:
+                gradsink.done(weight)
+            if bsink is not None:
+                gradsink.done(ctx.bias_ref)
         return dx, dw, db, dx2, None
 
 
@@ -210,6 +231,9 @@ class _HeadConv(torch.autograd.Function):
                                              _lib.stream()), "dvs_conv2d_head_fwd")
         ctx.cfg = (pad, reflect, act, bias is not None)
         ctx.pooled = weight.grad is not None and (bias is None or bias.grad is not None)
+        ctx.params = (weight, bias)              # only to find their gradient sinks in backward
+        if ctx.needs_input_grad[1]:
+            gradsink.begin(weight, bias)
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -221,11 +245,20 @@ class _HeadConv(torch.autograd.Function):
         d = _desc(B, Cin, H, W, w.shape, 1, pad, reflect)
         dy = _nhwc(dy)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
-        db = zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None
+        wsink, bsink = gradsink.target(ctx.params[0]), gradsink.target(ctx.params[1])
+        if wsink is not None and not wsink.permute(0, 2, 3, 1).is_contiguous():
+            wsink = None
+        dw = wsink if wsink is not None else zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
+        db = bsink if bsink is not None else (zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None)
         check(_lib.lib().dvs_conv2d_head_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(),
                                              dx.data_ptr() if dx is not None else None, dw.data_ptr(), ptr(db), C.byref(d),
                                              ACT[act], _lib.stream()), "dvs_conv2d_head_bwd")
+        if wsink is not None:
+            gradsink.done(ctx.params[0])
+            dw = None
+        if bsink is not None:
+            gradsink.done(ctx.params[1])
+            db = None
         return dx, dw, db, None, None, None
 
 

@@ -20,9 +20,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-                                   float* __restrict__ invstd_out, int C) {
+                                   float* __restrict__ invstd_out, int C, long long* __restrict__ num_batches_tracked) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
     float mean = stats[c] / count;
     float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);     // biased, as used for normalisation
     float invstd = rsqrtf(var + eps);
@@ -157,7 +158,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_sum_partials_kernel(const float* __
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ du, const float* __restrict__ y,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                          float* __restrict__ dy, size_t n4, int C, float inv_count) {
+                                                          float* __restrict__ dy, size_t n4, int C, float inv_count,
+                                                          float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+    if (blockIdx.x == 0 && dgamma_acc) {               // gradient sink: d gamma / d beta added straight into .grad
+        for (int c = threadIdx.x; c < C; c += NT) {
+            dbeta_acc[c] += sums[c];
+            dgamma_acc[c] += sums[C + c];
+        }
+    }
     size_t stride = (size_t)gridDim.x * NT;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
         int c = (int)((i * 4) % C);
@@ -187,11 +195,12 @@ extern "C" {
 
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                    float* invstd, int C, void* stream) {
+                    float* invstd, int C, long long* num_batches_tracked, void* stream) {
     DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1, "dvs_bn_finalize: bad argument");
     DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_finalize: running stats come together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), stats,
-                       (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C);
+                       (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C,
+                       num_batches_tracked);
     return dvs::check_launch("dvs_bn_finalize");
 }
 
@@ -247,13 +256,14 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
 }
 
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* sums, float* dy, size_t M, int C, void* stream) {
+                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, void* stream) {
     DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0, "dvs_bn_bwd_apply: bad argument");
+    DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_bwd_apply: gradient sinks come together");
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
-                       C, (float)(1.0 / (double)M));
+                       C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
     return dvs::check_launch("dvs_bn_bwd_apply");
 }
 

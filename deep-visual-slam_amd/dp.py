@@ -19,7 +19,7 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, gradsink
 from ._lib import check, ptr
 
 
@@ -35,7 +35,10 @@ def trainable_parameters(*modules):
 
 
 class FlatParams:
-    def __init__(self, named_params, align=4):
+    def __init__(self, named_params, align=4, grad_sinks=True):
+        """grad_sinks: let the weight-gradient / BatchNorm kernels accumulate straight into the gradient arena
+        (gradsink.py).  Requires training with `loss.backward()`; `torch.autograd.grad` w.r.t. these parameters
+        would see None."""
         named_params = list(named_params)[::-1]          # reverse construction order = backward order
         self.names = [n for n, _ in named_params]
         self.tensors = [p for _, p in named_params]
@@ -53,6 +56,8 @@ class FlatParams:
             self._view(self.params, p, o).copy_(p.data)
             p.data = self._view(self.params, p, o)
             p.grad = self._view(self.grads, p, o)
+            if grad_sinks:
+                gradsink.attach(p, p.grad)
 
     @staticmethod
     def _view(flat, p, o):
@@ -72,6 +77,8 @@ class FlatParams:
         for p, o in zip(self.tensors, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + 4 * o:
                 p.grad = self._view(self.grads, p, o)
+                if getattr(p, "_dvs_sink", None) is not None:
+                    p._dvs_sink.grad = p.grad
 
 
 class GradSync:
@@ -98,7 +105,11 @@ class GradSync:
         self._work = []
         if self.world > 1:
             for i, p in enumerate(flat.tensors):
-                p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
+                hook = self._make_hook(self.bucket_of[i])
+                p.register_post_accumulate_grad_hook(hook)       # gradients that arrive through autograd ...
+                sink = getattr(p, "_dvs_sink", None)
+                if sink is not None:
+                    sink.on_ready = hook                         # ... and those the kernels accumulate in place
 
     def _make_hook(self, b):
         def hook(_param):
@@ -120,6 +131,10 @@ class GradSync:
                 w.wait()
         self._work = []
         self._ready = [0] * len(self.buckets)
+        for p in self.flat.tensors:
+            sink = getattr(p, "_dvs_sink", None)
+            if sink is not None:
+                sink.pending = 0
 
     @property
     def grad_scale(self):

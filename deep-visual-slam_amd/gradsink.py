@@ -1,0 +1,58 @@
+"""Gradient sinks: parameter gradients accumulated in place by the kernel that produces them.
+
+With a persistent `.grad` (dp.FlatParams keeps every gradient in one flat arena that the fused Adam pass
+re-zeroes), autograd's AccumulateGrad is one zero-fill of a scratch tensor plus one `grad += scratch` launch
+per parameter use: ~360 five-microsecond launches per training step (2.2 ms of GPU time, more on the
+host).  The split-K weight-gradient kernels already accumulate with atomics and the BatchNorm backward
+owns its channel sums, so they can add straight into `.grad` instead; the autograd Function then returns
+None for that parameter.
+
+A sink is opt-in per parameter (`attach`, done by dp.FlatParams) because it changes what
+`torch.autograd.grad` sees: sunk gradients only ever reach `.grad`, i.e. train with `loss.backward()`.
+`on_ready` replaces the post-accumulate-grad hook for sunk parameters: it fires when the last use recorded
+in the forward has been accumulated (PoseNet runs twice per step, so its parameters have two uses).
+"""
+
+
+class Sink:
+    __slots__ = ("grad", "pending", "on_ready")
+
+    def __init__(self, grad):
+        self.grad = grad
+        self.pending = 0
+        self.on_ready = None
+
+
+def attach(param, grad_view):
+    param._dvs_sink = Sink(grad_view)
+    return param._dvs_sink
+
+
+def target(param):
+    """The tensor to accumulate into, or None when the parameter has no (live) sink."""
+    if param is None:
+        return None
+    s = getattr(param, "_dvs_sink", None)
+    if s is None or param.grad is None or param.grad.data_ptr() != s.grad.data_ptr():
+        return None
+    return s.grad
+
+
+def begin(*params):
+    """Forward: record one pending use of each sunk parameter."""
+    for p in params:
+        if target(p) is not None:
+            p._dvs_sink.pending += 1
+
+
+def done(*params):
+    """Backward: one use of each parameter has been accumulated into its sink."""
+    for p in params:
+        s = getattr(p, "_dvs_sink", None) if p is not None else None
+        if s is None:
+            continue
+        s.pending -= 1
+        if s.pending <= 0:
+            s.pending = 0
+            if s.on_ready is not None:
+                s.on_ready(p)

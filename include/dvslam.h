@@ -140,16 +140,21 @@ int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const fl
  *     (torchvision BasicBlock tail used by model/resnet_encoder.py:100-111).  `stats` = [2][C] per-channel
  *     sum / sum of squares of y as accumulated by dvs_conv2d_fwd's epilogue; count = B*H*W.
  *       finalize : mean, invstd = rsqrt(biased var + eps); scale = gamma*invstd; shift = beta - mean*scale;
- *                  running_mean/var updated with `momentum` (unbiased var), NULL = leave them.
+ *                  running_mean/var updated with `momentum` (unbiased var), NULL = leave them;
+ *                  *num_batches_tracked (int64, NULL = skip) is incremented, as nn.BatchNorm2d does.
  *       apply_fwd: z = [relu](y*scale + shift [+ residual | + residual*res_scale + res_shift]).
  *       bwd_reduce: du = dz * [z > 0] (z NULL = no ReLU; du NULL = do not store); sums[0][c] += sum du,
- *                  sums[1][c] += sum du * xhat (= d beta, d gamma); caller zero-fills sums.
- *       bwd_apply: dy = gamma * invstd * (du - sums0/M - xhat * sums1/M).
+ *                  sums[1][c] += sum du * xhat (= d beta, d gamma); caller zero-fills sums.  Each workgroup
+ *                  writes one partial row into `workspace` (dvs_bn_bwd_workspace bytes), a second small
+ *                  kernel adds the rows into sums (same-address float atomics serialise at ~85 ns each).
+ *       bwd_apply: dy = gamma * invstd * (du - sums0/M - xhat * sums1/M); dgamma_acc / dbeta_acc (both or
+ *                  neither, NULL = skip): d gamma += sums1, d beta += sums0, i.e. the parameter gradients are
+ *                  accumulated in place (what autograd's AccumulateGrad would do with one more launch each).
  *     M = pixels (rows), C % 4 == 0 and C/4 divides 256 (C in {16..1024}).
  * ------------------------------------------------------------------------------------------- */
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                    float* invstd, int C, void* stream);
+                    float* invstd, int C, long long* num_batches_tracked, void* stream);
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
                      const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu,
                      void* stream);
@@ -158,7 +163,8 @@ size_t dvs_bn_bwd_workspace(size_t M, int C);
 int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                       float* du, float* sums, float* workspace, size_t M, int C, void* stream);
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* sums, float* dy, size_t M, int C, void* stream);
+                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion
