@@ -10,6 +10,8 @@ materialised lazily on first access (or eagerly with config["Train"]["materializ
 """
 from typing import Dict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -60,6 +62,14 @@ class MonodepthTrainer:
         self.materialize_outputs = bool(tr.get("materialize_outputs", False))
         self.noise_seed = int(tr.get("noise_seed", 0))
         self._step = 0
+        # DepthNet and PoseNet are independent until the loss chain joins them: PoseNet's forward -- and, because
+        # autograd replays a node on the stream of its forward, its backward too -- runs on a second HIP stream, so
+        # the two networks' kernels fill each other's tails (a 450-workgroup conv on 256 CUs leaves 12 % of the chip
+        # idle in its last round) and the many small launches of one hide behind the other's convolutions.
+        # The two PoseNet passes stay in order on that one stream (they update the same BatchNorm running statistics).
+        use_stream = tr.get("pose_stream", os.environ.get("DVS_POSE_STREAM", "1") != "0")
+        self.pose_stream = (torch.cuda.Stream(device=self.device)
+                            if use_stream and torch.device(self.device).type == "cuda" else None)
         self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]
 
         # standalone operators kept as public attributes like the reference (learner_new.py:44-57)
@@ -78,8 +88,19 @@ class MonodepthTrainer:
             if isinstance(sample[key], torch.Tensor):
                 sample[key] = sample[key].to(self.device, non_blocking=True)
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
-        outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
-        outputs.update(self._predict_poses(sample))
+        if self.pose_stream is None:
+            outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
+            outputs.update(self._predict_poses(sample))
+        else:
+            main = torch.cuda.current_stream(self.device)
+            self.pose_stream.wait_stream(main)                   # inputs, zeroed scratch, last step's weights
+            with torch.cuda.stream(self.pose_stream):
+                poses = self._predict_poses(sample)
+            outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
+            main.wait_stream(self.pose_stream)
+            for t in poses.values():
+                t.record_stream(main)                            # allocated on the pose stream, read by the chain
+            outputs.update(poses)
         losses = self._fused_losses(sample, outputs)
         return outputs, losses
 
