@@ -207,13 +207,27 @@ class _Conv2d(torch.autograd.Function):
             # pool-backed scratch only when autograd will add it into an existing .grad (never adopt it)
             wsink = None if planar else gradsink.target(weight)
             bsink = None if planar else gradsink.target(ctx.bias_ref)
-            dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
-                                  in_scale=scale, in_shift=shift, nchw_planar=planar, pooled=weight.grad is not None,
-                                  dw_out=wsink, db_out=bsink)
-            if wsink is not None:
-                gradsink.done(weight)
-            if bsink is not None:
-                gradsink.done(ctx.bias_ref)
+            # fully sunk (nothing goes back to autograd): run beside the data-gradient chain on the side stream
+            side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
+            if side is None:
+                dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
+                                      in_scale=scale, in_shift=shift, nchw_planar=planar,
+                                      pooled=weight.grad is not None, dw_out=wsink, db_out=bsink)
+                if wsink is not None:
+                    gradsink.done(weight)
+                if bsink is not None:
+                    gradsink.done(ctx.bias_ref)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
+                                 in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink)
+                    gradsink.done(weight)                    # a ready-hook launched here orders itself after `side`
+                    if bsink is not None:
+                        gradsink.done(ctx.bias_ref)
+                for t in (x, dy, y, x2):
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)                # keep the allocator from recycling them under the kernel
         return dx, dw, db, dx2, None
 
 

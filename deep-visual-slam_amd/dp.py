@@ -122,6 +122,7 @@ class GradSync:
 
     def finish(self):
         """Wait for the step's all-reduces (any bucket whose hooks did not all fire is reduced now)."""
+        gradsink.join()                      # weight gradients accumulated on side streams
         if self.world > 1:
             for b, (s, e) in enumerate(self.buckets):
                 if self._ready[b] != self.sizes[b]:
@@ -154,6 +155,7 @@ class FusedAdam:
 
     def step(self, grad_scale=1.0, zero_grad=True):
         self.step_count += 1
+        gradsink.join()                      # weight gradients accumulated on side streams
         lr = self.param_groups[0]["lr"]
         f = self.flat
         check(_lib.lib().dvs_adam_step(ptr(f.params), ptr(f.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),

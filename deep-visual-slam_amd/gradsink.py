@@ -56,3 +56,38 @@ def done(*params):
             s.pending = 0
             if s.on_ready is not None:
                 s.on_ready(p)
+
+
+# ---------------------------------------------------------------------------------------------
+# Side streams for sunk weight gradients.  A weight gradient is needed by nobody until the optimiser step, so
+# when it is accumulated in place (no tensor handed back to autograd) its kernel can run on a side stream next
+# to the data-gradient chain that the rest of backward is waiting for.  One side stream per compute stream.
+# `join()` makes the current stream wait for all of them: call it before reading the gradients (dp.FusedAdam.step
+# and dp.GradSync.finish do) and before the scratch pool is recycled (MonodepthTrainer.process_batch does).
+# ---------------------------------------------------------------------------------------------
+import os
+
+import torch
+
+_side = {}
+_enabled = os.environ.get("DVS_WGRAD_STREAM", "1") != "0"
+
+
+def side_stream():
+    """Side stream paired with the current stream, or None when disabled."""
+    if not _enabled:
+        return None
+    cur = torch.cuda.current_stream()
+    key = (cur.device_index, cur.cuda_stream)
+    s = _side.get(key)
+    if s is None:
+        s = _side[key] = torch.cuda.Stream(device=cur.device)
+    return s
+
+
+def join():
+    if _side:
+        cur = torch.cuda.current_stream()
+        for (dev, _), s in _side.items():
+            if dev == cur.device_index:
+                cur.wait_stream(s)

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops, zeropool
+from . import gradsink, ops, zeropool
 from .layers import SSIM, BackprojectDepth, Project3D
 
 
@@ -87,6 +87,7 @@ class MonodepthTrainer:
         for key in sample:
             if isinstance(sample[key], torch.Tensor):
                 sample[key] = sample[key].to(self.device, non_blocking=True)
+        gradsink.join()                                          # side-stream kernels of the previous step
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
         if self.pose_stream is None:
             outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
