@@ -116,6 +116,7 @@ class GradSync:
             self._ready[b] += 1
             if self._ready[b] == self.sizes[b]:
                 s, e = self.buckets[b]
+                gradsink.fence()         # the bucket's gradients were written on several streams
                 self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
         return hook

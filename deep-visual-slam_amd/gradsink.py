@@ -69,7 +69,7 @@ import os
 
 import torch
 
-_side = {}
+_side = {}          # (device index, compute stream handle) -> (compute stream, its side stream)
 _enabled = os.environ.get("DVS_WGRAD_STREAM", "1") != "0"
 
 
@@ -79,15 +79,31 @@ def side_stream():
         return None
     cur = torch.cuda.current_stream()
     key = (cur.device_index, cur.cuda_stream)
-    s = _side.get(key)
-    if s is None:
-        s = _side[key] = torch.cuda.Stream(device=cur.device)
-    return s
+    pair = _side.get(key)
+    if pair is None:
+        pair = _side[key] = (cur, torch.cuda.Stream(device=cur.device))
+    return pair[1]
 
 
 def join():
+    """The current stream waits for every side stream of its device."""
     if _side:
         cur = torch.cuda.current_stream()
-        for (dev, _), s in _side.items():
+        for (dev, _), (_, side) in _side.items():
             if dev == cur.device_index:
-                cur.wait_stream(s)
+                cur.wait_stream(side)
+
+
+def fence():
+    """The current stream waits for every stream that can hold gradient-producing work: the side streams AND their
+    compute streams (BatchNorm / head gradients are accumulated on the compute stream, DepthNet and PoseNet use
+    different ones).  Used before a gradient bucket is handed to the all-reduce."""
+    if _side:
+        cur = torch.cuda.current_stream()
+        for (dev, handle), (comp, side) in _side.items():
+            if dev != cur.device_index:
+                continue
+            if side.cuda_stream != cur.cuda_stream:
+                cur.wait_stream(side)
+            if handle != cur.cuda_stream:
+                cur.wait_stream(comp)
