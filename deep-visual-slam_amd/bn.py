@@ -44,10 +44,6 @@ class _BNAct(torch.autograd.Function):
                                  int(relu), _lib.stream()), "dvs_bn_apply_fwd")
         ctx.relu = relu
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
-        if ctx.needs_input_grad[1]:
-            gradsink.begin(gamma, beta)
-            if res_fin is not None:
-                gradsink.begin(res_gamma, res_beta)
         ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
         return z
 
@@ -75,7 +71,6 @@ class _BNAct(torch.autograd.Function):
               "dvs_bn_bwd_apply")
         if sunk:
             d_gamma = d_beta = None
-            gradsink.done(g_par, b_par)
         else:
             d_gamma, d_beta = sums[1], sums[0]
         d_res = d_rg = d_rb = None
@@ -92,9 +87,7 @@ class _BNAct(torch.autograd.Function):
                 check(l.dvs_bn_bwd_apply(du.data_ptr(), residual.data_ptr(), res_fin[2].data_ptr(), res_fin[3].data_ptr(),
                                          ptr(res_gamma), ptr(rsums), d_res.data_ptr(), M, C, ptr(gs) if sunk else None,
                                          ptr(bs) if sunk else None, st), "dvs_bn_bwd_apply")
-                if sunk:
-                    gradsink.done(rg_par, rb_par)
-                else:
+                if not sunk:
                     d_rg, d_rb = rsums[1], rsums[0]
         return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None
 

@@ -173,8 +173,6 @@ class _Conv2d(torch.autograd.Function):
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                      # only to find its gradient sink in backward
-        if ctx.needs_input_grad[1] and not planar:
-            gradsink.begin(weight, bias)
         ctx.up_only = x2 is UPSAMPLE_ONLY
         ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
         if want_stats:
@@ -213,18 +211,11 @@ class _Conv2d(torch.autograd.Function):
                 dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
                                       in_scale=scale, in_shift=shift, nchw_planar=planar,
                                       pooled=weight.grad is not None, dw_out=wsink, db_out=bsink)
-                if wsink is not None:
-                    gradsink.done(weight)
-                if bsink is not None:
-                    gradsink.done(ctx.bias_ref)
             else:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
                                  in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink)
-                    gradsink.done(weight)                    # a ready-hook launched here orders itself after `side`
-                    if bsink is not None:
-                        gradsink.done(ctx.bias_ref)
                 for t in (x, dy, y, x2):
                     if isinstance(t, torch.Tensor):
                         t.record_stream(side)                # keep the allocator from recycling them under the kernel
@@ -246,8 +237,6 @@ class _HeadConv(torch.autograd.Function):
         ctx.cfg = (pad, reflect, act, bias is not None)
         ctx.pooled = weight.grad is not None and (bias is None or bias.grad is not None)
         ctx.params = (weight, bias)              # only to find their gradient sinks in backward
-        if ctx.needs_input_grad[1]:
-            gradsink.begin(weight, bias)
         ctx.save_for_backward(x, w, y)
         return y
 
@@ -268,10 +257,8 @@ class _HeadConv(torch.autograd.Function):
                                              dx.data_ptr() if dx is not None else None, dw.data_ptr(), ptr(db), C.byref(d),
                                              ACT[act], _lib.stream()), "dvs_conv2d_head_bwd")
         if wsink is not None:
-            gradsink.done(ctx.params[0])
             dw = None
         if bsink is not None:
-            gradsink.done(ctx.params[1])
             db = None
         return dx, dw, db, None, None, None
 

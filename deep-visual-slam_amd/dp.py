@@ -102,20 +102,20 @@ class GradSync:
         for b in self.bucket_of:
             self.sizes[b] += 1
         self._ready = [0] * len(self.buckets)
+        self._reduced = [False] * len(self.buckets)
         self._work = []
         if self.world > 1:
+            # fires once per backward, after the last use of the parameter -- also for sunk gradients, whose
+            # Functions hand None to autograd (gradsink.py)
             for i, p in enumerate(flat.tensors):
-                hook = self._make_hook(self.bucket_of[i])
-                p.register_post_accumulate_grad_hook(hook)       # gradients that arrive through autograd ...
-                sink = getattr(p, "_dvs_sink", None)
-                if sink is not None:
-                    sink.on_ready = hook                         # ... and those the kernels accumulate in place
+                p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
 
     def _make_hook(self, b):
         def hook(_param):
             self._ready[b] += 1
-            if self._ready[b] == self.sizes[b]:
+            if self._ready[b] == self.sizes[b] and not self._reduced[b]:
                 s, e = self.buckets[b]
+                self._reduced[b] = True
                 gradsink.fence()         # the bucket's gradients were written on several streams
                 self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
@@ -123,20 +123,17 @@ class GradSync:
 
     def finish(self):
         """Wait for the step's all-reduces (any bucket whose hooks did not all fire is reduced now)."""
-        gradsink.join()                      # weight gradients accumulated on side streams
+        gradsink.fence()                     # gradients accumulated on the side / per-network streams
         if self.world > 1:
             for b, (s, e) in enumerate(self.buckets):
-                if self._ready[b] != self.sizes[b]:
+                if not self._reduced[b]:
                     self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                       async_op=True))
             for w in self._work:
                 w.wait()
         self._work = []
         self._ready = [0] * len(self.buckets)
-        for p in self.flat.tensors:
-            sink = getattr(p, "_dvs_sink", None)
-            if sink is not None:
-                sink.pending = 0
+        self._reduced = [False] * len(self.buckets)
 
     @property
     def grad_scale(self):

@@ -9,18 +9,17 @@ None for that parameter.
 
 A sink is opt-in per parameter (`attach`, done by dp.FlatParams) because it changes what
 `torch.autograd.grad` sees: sunk gradients only ever reach `.grad`, i.e. train with `loss.backward()`.
-`on_ready` replaces the post-accumulate-grad hook for sunk parameters: it fires when the last use recorded
-in the forward has been accumulated (PoseNet runs twice per step, so its parameters have two uses).
+"Gradient complete" notifications need nothing extra: autograd runs a parameter's AccumulateGrad node -- and
+with it the post-accumulate-grad hooks dp.GradSync registers -- after the last Function that uses the parameter
+has returned, also when every one of them returned None (tests/test_dp_cpu.py pins that behaviour).
 """
 
 
 class Sink:
-    __slots__ = ("grad", "pending", "on_ready")
+    __slots__ = ("grad",)
 
     def __init__(self, grad):
         self.grad = grad
-        self.pending = 0
-        self.on_ready = None
 
 
 def attach(param, grad_view):
@@ -36,26 +35,6 @@ def target(param):
     if s is None or param.grad is None or param.grad.data_ptr() != s.grad.data_ptr():
         return None
     return s.grad
-
-
-def begin(*params):
-    """Forward: record one pending use of each sunk parameter."""
-    for p in params:
-        if target(p) is not None:
-            p._dvs_sink.pending += 1
-
-
-def done(*params):
-    """Backward: one use of each parameter has been accumulated into its sink."""
-    for p in params:
-        s = getattr(p, "_dvs_sink", None) if p is not None else None
-        if s is None:
-            continue
-        s.pending -= 1
-        if s.pending <= 0:
-            s.pending = 0
-            if s.on_ready is not None:
-                s.on_ready(p)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -102,3 +102,26 @@ def test_fc_head_is_excluded():
     named = dp.trainable_parameters(DepthNet(18, False), PoseNet(18, False, 2))
     assert sum(p.numel() for _, p in named) == 26828186
     assert not any(".fc." in n for n, _ in named)
+
+
+def test_post_accumulate_hook_fires_for_none_gradients():
+    """dp.GradSync counts a parameter as complete when its post-accumulate-grad hook fires.  Gradient sinks
+    (gradsink.py) make the autograd Functions return None for their parameters; the hook must still fire, once,
+    after the last use."""
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            return g, None
+
+    w = torch.nn.Parameter(torch.ones(3))
+    w.grad = torch.zeros(3)
+    x = torch.ones(3, requires_grad=True)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+    (F.apply(x, w) + F.apply(2 * x, w)).sum().backward()
+    assert fired == [1]
+    assert float(w.grad.abs().max()) == 0.0
