@@ -65,6 +65,21 @@ def gpu_step(trainer, sync, opt, sample):
     return losses
 
 
+def pmc_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
+    (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the timed run, so the
+    number travels as profiles/traffic_<config>.json; null when that file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_%s.json" % config)
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][kernel]
+        return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (PMC)",
+                "traffic_source": "profiles/traffic_%s.json" % config}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def cpu_baseline(batch, num_scales, steps=2, warmup=1):
     """The reference's step on host cores: oracle networks + oracle loss chain + torch.optim.Adam."""
     from deep_visual_slam_amd import synth
@@ -118,6 +133,11 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[1] side measurement")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-launch HIP-event steps after the timed region (no roofline object in the output)")
+    ap.add_argument("--serialize", action="store_true",
+                    help="run the timed region on one stream too (what the rocprofv3 per-kernel passes use)")
     args = ap.parse_args()
 
     cfg = CONFIGS[args.config]
@@ -151,17 +171,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def set_concurrency(on):
+        """Multi-stream execution (PoseNet stream, weight-gradient side streams) on / off."""
+        from deep_visual_slam_amd import gradsink
+        torch.cuda.synchronize()
+        gradsink.enable_side_streams(on)
+        trainer.pose_stream = pose_stream if on else None
+
+    pose_stream = trainer.pose_stream
+    if args.serialize:
+        set_concurrency(False)
     for _ in range(args.warmup):
         gpu_step(trainer, sync, opt, sample)
     barrier()
-    dp.profile_enable(True)
+    # timed region: K steps, nothing else (no per-launch events)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = gpu_step(trainer, sync, opt, sample)
     barrier()
     dt = time.perf_counter() - t0
-    prof = dp.profile_read()
-    dp.profile_enable(False)
+    # per-kernel durations for the roofline: HIP events around every launch of the library, over further steps
+    # of the same loop run on ONE stream -- with DepthNet, PoseNet and the weight gradients overlapping on four
+    # streams an event pair measures how long a kernel shared the chip, not how long it needs
+    prof, prof_steps = {}, 0
+    if not args.no_kernel_timing:
+        set_concurrency(False)
+        gpu_step(trainer, sync, opt, sample)
+        barrier()
+        dp.profile_enable(True)
+        prof_steps = max(1, min(args.steps, 5))
+        for _ in range(prof_steps):
+            gpu_step(trainer, sync, opt, sample)
+        barrier()
+        prof = dp.profile_read()
+        dp.profile_enable(False)
+        set_concurrency(not args.serialize)
     loss_val = float(losses["loss"].detach())
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -174,7 +218,7 @@ def main():
     if rank == 0:
         # roofline of the dominant hand-written kernel inside the timed region
         per_kernel = {k: (ms / n, n) for k, (ms, n, _) in prof.items()}
-        per_step = {k: ms / args.steps for k, (ms, n, _) in prof.items()}
+        per_step = {k: ms / prof_steps for k, (ms, n, _) in prof.items()}
         dom = max(prof, key=lambda k: prof[k][0]) if prof else None      # most time inside the timed region
         roof = None
         if dom in ("chain_fwd_kernel", "chain_bwd_kernel"):
@@ -191,25 +235,48 @@ def main():
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": ms / n,
-                    "launches_per_step": n / args.steps, "algorithmic_flops_per_step": flops / args.steps}
+                    "launches_per_step": n / prof_steps, "algorithmic_flops_per_step": flops / prof_steps}
         all_conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
         conv_summary = None
         if all_conv:
-            conv_summary = {k: {"ms_per_step": v[0] / args.steps, "tflops": v[2] / (v[0] * 1e-3) / 1e12}
+            conv_summary = {k: {"ms_per_step": v[0] / prof_steps, "tflops": v[2] / (v[0] * 1e-3) / 1e12}
                             for k, v in all_conv.items()}
+        if roof is not None:
+            roof["measured"] = ("HIP events on the launch stream, %d single-stream steps after the timed region "
+                                "(the timed steps overlap four streams)" % prof_steps)
+            roof.update(pmc_traffic(args.config, roof["kernel"]))
         out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": cfg["name"], "per_gpu_batch": batch, "global_batch": batch * world,
                           "num_scales": num_scales, "image": "%dx%d" % (W, H),
-                          "parallelism": "dp%d" % world, "conv_backend": os.environ.get("DVS_CONV_BACKEND", "hip")},
+                          "parallelism": "dp%d" % world, "conv_backend": os.environ.get("DVS_CONV_BACKEND", "hip"),
+                          "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient"},
                "loss": loss_val,
                "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
                "conv_kernels": conv_summary,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, num_scales)
+        if world == 1 and args.config == "c3" and not args.no_other_configs:
+            # BASELINE.json configs[1] (batch 4, single-scale loss) beside the headline workload: same code path,
+            # same timing discipline, reported for reference -- `value` above is the batch-12 4-scale step
+            del trainer, flat, sync, opt, sample, losses
+            torch.cuda.empty_cache()
+            c2 = CONFIGS["c2"]
+            tr2, _, sync2, opt2, sample2 = build_gpu(c2["batch"], c2["num_scales"], device, rank)
+            for _ in range(args.warmup):
+                gpu_step(tr2, sync2, opt2, sample2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                gpu_step(tr2, sync2, opt2, sample2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            out["other_configs"] = {"configs[1]": {"workload": c2["name"], "value": 3.0 * c2["batch"] * args.steps / dt2,
+                                                   "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
+                                                   "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"]}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -52,6 +52,14 @@ _side = {}          # (device index, compute stream handle) -> (compute stream, 
 _enabled = os.environ.get("DVS_WGRAD_STREAM", "1") != "0"
 
 
+def enable_side_streams(on):
+    """Turn the weight-gradient side streams on / off (off: every kernel runs on its compute stream, which is what
+    per-kernel timing wants)."""
+    global _enabled
+    join()
+    _enabled = bool(on)
+
+
 def side_stream():
     """Side stream paired with the current stream, or None when disabled."""
     if not _enabled:
