@@ -52,6 +52,21 @@ struct InXform {
                              //     3 sigmoid (y(1-y))
 };
 
+// Workgroup -> tile mapping.  Workgroups are dealt to the 8 XCDs round-robin in launch order (linear id L runs on
+// XCD L % 8) and every XCD has its own 4 MB L2, so two tiles that read the same operand rows -- the output rows r
+// and r+1 of a 3x3 conv share two input rows, the N tiles of one M tile share the whole im2col slice, the N tiles
+// of a weight-gradient split share its pixels -- only meet in an L2 if they run on the SAME XCD close in time.
+// The grids are therefore launched 1-D and XCD x works through the contiguous logical range [x*q, (x+1)*q) of
+// tile ids (bijective for any workgroup count).  grid3.w = 0 switches the remap off (DVS_CONV_XCD=0).
+struct Grid3 {
+    int x, y, z, remap;
+};
+__device__ __forceinline__ int xcd_logical(int L, int nwg, int remap) {
+    if (!remap) return L;
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // d act(u) / du expressed through the activation's OUTPUT y = act(u)
 __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     switch (act) {

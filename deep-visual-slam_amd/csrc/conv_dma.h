@@ -61,11 +61,15 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     ConvShape s = p.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);      // see conv_fwd_kernel
+    const int bid_y = lg % p.g.y;
+    lg /= p.g.y;
+    const int bid_z = lg % p.g.z, bid_x = lg / p.g.z;
+    const int m0 = bid_x * BM, n0 = bid_y * BN;
 
     int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0, kw_full = s.kw;
     if (MODE == IN_DGRAD && s.stride == 2) {         // parity classes, see conv_fwd_kernel
-        const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+        const int py = bid_z >> 1, px = bid_z & 1;
         oy0 = (py - s.pad) & 1;
         ox0 = (px - s.pad) & 1;
         Hr = (s.Ho - oy0 + 1) >> 1;

@@ -28,6 +28,7 @@ struct FwdParams {
     float* y2;           // data gradient of an upsample+concat conv: channels >= split_c1 go here ([B,H,W,Cout-C1]) ...
     int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
+    Grid3 g;             // logical grid: M tiles, N tiles, parity classes (launched 1-D, see xcd_logical)
     ConvShape s;
     InXform t;
     int act;
@@ -106,7 +107,12 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     ConvShape s = p.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // N tile fastest, then parity class, then M tile: the tiles that share an im2col slice are neighbours
+    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);
+    const int bid_y = lg % p.g.y;
+    lg /= p.g.y;
+    const int bid_z = lg % p.g.z, bid_x = lg / p.g.z;
+    const int m0 = bid_x * BM, n0 = bid_y * BN;
     const int c4 = (tid & 7) * 4, r0 = tid >> 3;            // my k-offset inside a stage, my first row
 
     // Row space.  Forward: output pixels.  Data gradient: input pixels -- for a stride-2 conv they are split
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     // own parity (ky = py + 2 jy), so the empty 3/4 of the strided im2col matrix is never multiplied.
     int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0, kw_full = s.kw;
     if (MODE == IN_DGRAD && s.stride == 2) {
-        const int py = blockIdx.z >> 1, px = blockIdx.z & 1;
+        const int py = bid_z >> 1, px = bid_z & 1;
         oy0 = (py - s.pad) & 1;
         ox0 = (px - s.pad) & 1;
         Hr = (s.Ho - oy0 + 1) >> 1;
@@ -282,6 +288,11 @@ bool dma_eligible(const FwdParams& p) {
     return true;
 }
 
+inline int xcd_remap_enabled() {
+    static const int on = [] { const char* e = getenv("DVS_CONV_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
+    return on;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
@@ -300,7 +311,9 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     dvs::ProfScope prof(slot, st);
     const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;
     prof.work(2.0 * M * p.s.Cout * (double)p.s.Ktot * eff);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+    FwdParams q = p;
+    q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
+    hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(NT), lds, st, q);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
@@ -338,7 +351,9 @@ void launch_buf(const FwdParams& p, hipStream_t st, int slot) {
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;   // strided taps are empty
     prof.work(2.0 * M * p.s.Cout * k_real * eff);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+    FwdParams q = p;
+    q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
+    hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(NT), lds, st, q);
 }
 
 template <int MODE, bool FOLD>

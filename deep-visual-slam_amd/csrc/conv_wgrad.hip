@@ -27,7 +27,8 @@ struct WgradParams {
     float* dbias;        // [Cout] or NULL
     ConvShape s;
     InXform t;           // forward input transform + (aux = Y, dact) for the dY side
-    int m_per_split;     // pixels per blockIdx.z, multiple of BP
+    int m_per_split;     // pixels per split, multiple of BP
+    Grid3 g;             // logical grid: Cout tiles, (tap,ci) tiles, pixel splits (launched 1-D, see xcd_logical)
     int dbg;             // timing experiment (DVS_CONV_DEBUG_NOBARRIER & 4): MFMA + LDS reads only -> wrong results
 };
 
@@ -45,9 +46,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int M = s.B * s.Ho * s.Wo;
-    const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
-    const int m_begin = blockIdx.z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
-    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0;
+    // Cout tile fastest, then (tap,ci) tile, then pixel split: the tiles of one split read the same pixels
+    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);
+    const int bid_x = lg % p.g.x;
+    lg /= p.g.x;
+    const int bid_y = lg % p.g.y, bid_z = lg / p.g.y;
+    const int co0 = bid_x * BM, k0 = bid_y * BN;
+    const int m_begin = bid_z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
+    const bool do_bias = p.dbias != nullptr && bid_y == 0;
 
     // dY side: my channel vector and pixel rows
     const int d_c = (tid % DV) * 4, d_p0 = tid / DV;        // rows d_p0 + (NT/DV) * j
@@ -211,8 +217,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int M = s.B * s.Ho * s.Wo;
-    const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN;
-    const int m_begin = blockIdx.z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
+    // Cout tile fastest, then (tap,ci) tile, then pixel split: the tiles of one split read the same pixels
+    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);
+    const int bid_x = lg % p.g.x;
+    lg /= p.g.x;
+    const int bid_y = lg % p.g.y, bid_z = lg / p.g.y;
+    const int co0 = bid_x * BM, k0 = bid_y * BN;
+    const int m_begin = bid_z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
 
     const int d_c = (lane % DV) * 4, d_r = lane / DV;       // my channel slice / pixel row inside an instruction
     const int co = co0 + d_c;
@@ -329,6 +340,8 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     splits = (M + mps - 1) / mps;
     p.m_per_split = mps;
     dim3 grid((p.s.Cout + BM - 1) / BM, (p.s.Ktot + BN - 1) / BN, splits);
+    static const int xcd_on = [] { const char* e = getenv("DVS_CONV_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
+    p.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_on};
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     prof.work(2.0 * M * p.s.Cout * k_real);
@@ -337,11 +350,11 @@ void launch_cfg(WgradParams p, hipStream_t st) {
         static const int dbg = getenv("DVS_CONV_DEBUG_NOBARRIER") ? atoi(getenv("DVS_CONV_DEBUG_NOBARRIER")) : 0;
         p.dbg = dbg & 4;
         if (dma && p.t.dact == 0 && p.dbias == nullptr) {
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), grid, dim3(NT), 0, st, p);
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
             return;
         }
     }
-    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
 }
 
 template <int MODE, bool FOLD>
