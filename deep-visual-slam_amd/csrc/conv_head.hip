@@ -11,6 +11,8 @@
 // Same NHWC layouts and [Cout][kh][kw][Cin] weights as the MFMA kernels (conv_common.h).
 #include "conv_common.h"
 
+#include <cstdlib>
+
 namespace {
 using namespace dvsconv;
 
@@ -210,11 +212,199 @@ __global__ __launch_bounds__(HNT) void head_wgrad_kernel(HeadParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-streaming forms (Cin/4 a power of two <= 64, COUT * k * k <= 18): lanes run along the channel dimension --
+// lane = (pixel slot, 4-channel chunk), a wave covers 64 / (Cin/4) neighbouring pixels -- so every tap is ONE fully
+// coalesced 16-byte-per-lane load of a contiguous 1 KB run of the NHWC row, the lane's weight slices (forward) or
+// gradient accumulators (weight gradient) live in registers for the whole kernel, and nothing is divided per pixel:
+// a workgroup walks whole image rows.  The forward reduces a pixel's chunks with log2(Cin/4) butterfly steps; the
+// weight gradient reduces pixel slots the same way, then the four waves through LDS, then one atomic per weight
+// and workgroup (<= 512 workgroups: same-address float atomics serialise at ~85 ns each).
+// ---------------------------------------------------------------------------------------------
+template <int COUT, int KS>
+__global__ __launch_bounds__(HNT) void head_fwd_rows_kernel(HeadParams p) {
+    constexpr int T = KS * KS;
+    const int cpl = p.Cin >> 2, ppb = HNT / cpl;                   // lanes per pixel, pixels per workgroup pass
+    const int kc = (threadIdx.x % cpl) * 4, slot = threadIdx.x / cpl;
+    f32x4 wr[COUT][T];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t) wr[c][t] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)c * T + t) * p.Cin + kc);
+    float bv[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) bv[c] = p.bias ? p.bias[c] : 0.f;
+    const int rows = p.B * p.H;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / p.H, oy = row - b * p.H;
+        const float* rp[KS];
+        bool rok[KS];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            bool v = true;
+            int iy = src_index(oy - p.pad + ky, p.H, p.reflect, v);
+            rok[ky] = v;
+            rp[ky] = p.x + ((size_t)b * p.H + iy) * p.W * p.Cin + kc;
+        }
+        for (int ox0 = 0; ox0 < p.W; ox0 += ppb) {
+            const int ox = ox0 + slot;
+            const bool px_ok = ox < p.W;
+            f32x4 v[T];
+            bool ok[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {                              // all taps in flight before any is used
+                bool vx = px_ok && rok[t / KS];
+                int ix = src_index(min(ox, p.W - 1) - p.pad + t % KS, p.W, p.reflect, vx);
+                ok[t] = vx;
+                v[t] = *reinterpret_cast<const f32x4*>(rp[t / KS] + (size_t)ix * p.Cin);
+            }
+            float acc[COUT];
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[c] = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float m = ok[t] ? 1.f : 0.f;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c)
+                    acc[c] = fmaf(m * v[t][0], wr[c][t][0], fmaf(m * v[t][1], wr[c][t][1],
+                             fmaf(m * v[t][2], wr[c][t][2], fmaf(m * v[t][3], wr[c][t][3], acc[c]))));
+            }
+            for (int off = cpl >> 1; off >= 1; off >>= 1)
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+            if (kc == 0 && px_ok) {
+                float* yp = p.y + ((size_t)row * p.W + ox) * COUT;
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) yp[c] = apply_act(acc[c] + bv[c], p.act);
+            }
+        }
+    }
+}
+
+template <int COUT, int KS>
+__global__ __launch_bounds__(HNT) void head_wgrad_rows_kernel(HeadParams p) {
+    constexpr int T = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) float sred[];       // [4 waves][cpl][COUT*T] float4 (+ bias sums)
+    const int cpl = p.Cin >> 2, ppb = HNT / cpl;
+    const int kq = threadIdx.x % cpl, kc = kq * 4, slot = threadIdx.x / cpl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[COUT][T];
+    float bsum[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        bsum[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int rows = p.B * p.H;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / p.H, oy = row - b * p.H;
+        const float* rp[KS];
+        bool rok[KS];
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            bool v = true;
+            int iy = src_index(oy - p.pad + ky, p.H, p.reflect, v);
+            rok[ky] = v;
+            rp[ky] = p.x + ((size_t)b * p.H + iy) * p.W * p.Cin + kc;
+        }
+        for (int ox0 = 0; ox0 < p.W; ox0 += ppb) {
+            const int ox = ox0 + slot;
+            const bool px_ok = ox < p.W;
+            const int oxc = min(ox, p.W - 1);
+            f32x4 v[T];
+            float m[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bool vx = px_ok && rok[t / KS];
+                int ix = src_index(oxc - p.pad + t % KS, p.W, p.reflect, vx);
+                m[t] = vx ? 1.f : 0.f;
+                v[t] = *reinterpret_cast<const f32x4*>(rp[t / KS] + (size_t)ix * p.Cin);
+            }
+            float g[COUT];
+            load_dyp<COUT>(p, (size_t)row * p.W + oxc, g);
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) {
+                g[c] = px_ok ? g[c] : 0.f;
+                bsum[c] += g[c];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float gm = g[c] * m[t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[c][t][j] = fmaf(gm, v[t][j], acc[c][t][j]);
+                }
+            }
+        }
+    }
+    // pixel slots of one wave: butterfly over the lane bits above the chunk index
+    for (int off = cpl; off < 64; off <<= 1) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) {
+            bsum[c] += __shfl_xor(bsum[c], off, 64);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[c][t][j] += __shfl_xor(acc[c][t][j], off, 64);
+        }
+    }
+    // the four waves through LDS (when a wave holds less than one pixel slot per chunk, cpl == 64, lanes map 1:1)
+    const int per_wave = cpl * COUT * T;                               // float4 entries
+    if (lane < cpl) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                *reinterpret_cast<f32x4*>(sred + ((size_t)wave * per_wave + (c * T + t) * cpl + lane) * 4) = acc[c][t];
+    }
+    float* sb = sred + (size_t)4 * per_wave * 4;                       // [4][COUT] bias partials
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) sb[wave * COUT + c] = bsum[c];
+    }
+    __syncthreads();
+    const int Ktot = T * p.Cin;
+    for (int e = threadIdx.x; e < per_wave; e += HNT) {                // e = (c*T + t)*cpl + chunk
+        f32x4 sum = *reinterpret_cast<const f32x4*>(sred + (size_t)e * 4);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4*>(sred + ((size_t)w * per_wave + e) * 4);
+        const int chunk = e % cpl, ct = e / cpl, t = ct % T, c = ct / T;
+        float* dst = p.dw + (size_t)c * Ktot + t * p.Cin + chunk * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sum[j]);
+    }
+    if (p.dbias && threadIdx.x < COUT)
+        atomicAdd(p.dbias + threadIdx.x, sb[threadIdx.x] + sb[COUT + threadIdx.x] + sb[2 * COUT + threadIdx.x] + sb[3 * COUT + threadIdx.x]);
+}
+
+inline bool rows_form_ok(const HeadParams& p, int cout) {
+    static const bool enabled = [] { const char* e = getenv("DVS_HEAD_ROWS"); return !(e && e[0] == '0'); }();
+    const int cpl = p.Cin / 4;
+    return enabled && cpl >= 1 && cpl <= 64 && (cpl & (cpl - 1)) == 0 && cout * p.k * p.k <= 18;
+}
+
+template <int COUT, int KS>
+void launch_rows(const HeadParams& p, int op, hipStream_t st) {
+    const int rows = p.B * p.H;
+    if constexpr (COUT * KS * KS <= 18) {
+        if (op == 0) {
+            hipLaunchKernelGGL((head_fwd_rows_kernel<COUT, KS>), dim3(rows < 4096 ? rows : 4096), dim3(HNT), 0, st, p);
+        } else {
+            const size_t lds = ((size_t)4 * (p.Cin / 4) * COUT * KS * KS * 4 + 4 * COUT) * sizeof(float);
+            hipLaunchKernelGGL((head_wgrad_rows_kernel<COUT, KS>), dim3(rows < 512 ? rows : 512), dim3(HNT), lds, st, p);
+        }
+    }
+}
+
 template <int COUT>
 int run(const HeadParams& p0, int op, hipStream_t st) {
     HeadParams p = p0;
     const int Ktot = p.k * p.k * p.Cin, M = p.B * p.H * p.W;
     const size_t wbytes = (size_t)COUT * Ktot * sizeof(float);
+    if (op != 1 && rows_form_ok(p, COUT)) {
+        if (p.k == 3) launch_rows<COUT, 3>(p, op, st);
+        else launch_rows<COUT, 1>(p, op, st);
+        return DVS_OK;
+    }
     if (op == 0) {
         if (p.k == 3) hipLaunchKernelGGL((head_fwd_kernel<COUT, 3>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
         else hipLaunchKernelGGL((head_fwd_kernel<COUT, 1>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
