@@ -91,8 +91,37 @@ def batch_norm(x, bn, relu=False, residual=None):
     return F.relu(y, inplace=True) if relu else y
 
 
+class _MaxPool3x3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on NHWC tensors (dvs_maxpool3x3s2_*): byte argmax forward, gather backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        idx = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().dvs_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), B, H, W, C, _lib.stream()),
+                   "dvs_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(_lib.lib().dvs_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, H, W, C, _lib.stream()),
+                   "dvs_maxpool3x3s2_bwd")
+        return dx
+
+
 def max_pool_3x3_s2(x):
     _require_gpu(x, "max_pool")
+    if x.shape[1] % 4 == 0 and x.dtype == torch.float32:
+        return _MaxPool3x3s2.apply(x)
     return F.max_pool2d(x, 3, 2, 1)
 
 

@@ -136,6 +136,15 @@ int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const fl
                         float* dbias, const dvs_conv_desc* d, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1  the ResNet stem's MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC tensors
+ *     (torchvision resnet18.maxpool reached through model/resnet_encoder.py:104).
+ *     x, dx: [B,H,W,C]; y, dy: [B,Ho,Wo,C] with Ho = (H-1)/2+1; idx: [B,Ho,Wo,C] bytes, the winning tap
+ *     ky*3+kx (first maximum in scan order, as torch); C % 4 == 0.  bwd writes every element of dx.
+ * ------------------------------------------------------------------------------------------- */
+int dvs_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, void* stream);
+int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a1  training-mode BatchNorm2d (+ residual add, + ReLU) of the ResNet BasicBlocks on NHWC tensors
  *     (torchvision BasicBlock tail used by model/resnet_encoder.py:100-111).  `stats` = [2][C] per-channel
  *     sum / sum of squares of y as accumulated by dvs_conv2d_fwd's epilogue; count = B*H*W.

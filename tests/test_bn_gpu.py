@@ -55,3 +55,24 @@ def test_conv_bn_act(gpu_device, C, H, W, mode):
     g_ref = torch.autograd.grad(z_ref, ins_ref, cot)
     for a, r, i in zip(g, g_ref, range(len(g))):
         assert rel(a, r) < 5e-4, (i, rel(a, r))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48, 64), (1, 16, 7, 9), (3, 8, 10, 5)])
+def test_maxpool_matches_torch_including_ties(gpu_device, shape):
+    """dvs_maxpool3x3s2_*: values bit-exact, and -- with half the inputs clamped to 0 as after the stem's ReLU --
+    gradients routed to the same (first) maximum as torch's kernel."""
+    import torch.nn.functional as F
+    from deep_visual_slam_amd import nn_ops
+    torch.manual_seed(4)
+    x = torch.relu(torch.randn(*shape, device=gpu_device)).contiguous(memory_format=torch.channels_last)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y1 = nn_ops.max_pool_3x3_s2(x1)
+    y2 = F.max_pool2d(x2, 3, 2, 1)
+    assert y1.shape == y2.shape and torch.equal(y1, y2)
+    g = torch.randn_like(y2)
+    y1.backward(g)
+    y2.backward(g)
+    # torch scatters with atomics (any order), this gathers in a fixed order: same terms, last-bit differences;
+    # a different tie rule would move whole gradient values between pixels
+    assert torch.allclose(x1.grad, x2.grad, rtol=1e-6, atol=1e-6)
+    assert torch.equal(x1.grad != 0, x2.grad != 0)
