@@ -340,4 +340,9 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
     }
 }
 
+// conv_stem.hip: kernels specialised for the ResNet stems (7x7, stride 2, planar 3- / 6-channel image -> 64 channels)
+bool stem_shape(const ConvShape& s);
+void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, const float* sc, const float* sh,
+                hipStream_t st);
+
 }  // namespace dvsconv

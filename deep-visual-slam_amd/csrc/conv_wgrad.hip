@@ -396,7 +396,11 @@ int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, c
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
-    if (planar) {
+    if (planar && stem_shape(s) && dact == 0 && dbias == nullptr && !p.t.in_relu) {
+        dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
+        prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
+        stem_wgrad(x, dy, dw, s, p.t.in_scale, p.t.in_shift, st);
+    } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st);
         else launch_mode<IN_PLANAR, false>(p, st);
     } else if (p.t.x2) {
