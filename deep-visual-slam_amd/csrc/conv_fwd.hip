@@ -473,7 +473,11 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
-    if (planar) {
+    if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE) {
+        dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
+        prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
+        stem_fwd(x, w, y, p.stats, s, p.t.in_scale, p.t.in_shift, st);
+    } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st, dvs::SLOT_CONV_FWD);
         else launch_mode<IN_PLANAR, false>(p, st, dvs::SLOT_CONV_FWD);
     } else if (p.t.x2) {

@@ -70,6 +70,60 @@ __device__ __forceinline__ void load_patch(const StemParams& p, float* patch, in
     }
 }
 
+// Everything about a thread's patch elements that does not depend on the tile is computed once: the element's
+// offset from the tile's image origin, its (row, column) inside the patch for the bounds test, and its channel's
+// normalisation.  Per tile and element that leaves two compares, a select and the load.
+template <int CIN>
+struct PatchPlan {
+    static constexpr int N = CIN * PROWS * PSTRIDE, U = (N + SNT - 1) / SNT;
+    int rel[U];            // ci * H * W + j * W + i
+    int ji[U];             // j << 16 | i   (i >= PCOLS marks a padding column: never valid)
+    float sc[U], sh[U];
+    __device__ __forceinline__ void init(int H, int W, const float* scp, const float* shp) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min((int)threadIdx.x + u * SNT, N - 1);
+            const int i = e % PSTRIDE, j = (e / PSTRIDE) % PROWS, ci = e / (PSTRIDE * PROWS);
+            rel[u] = (ci * H + j) * W + i;
+            ji[u] = (j << 16) | (i < PCOLS ? i : 0x7fff);
+            sc[u] = scp ? scp[ci] : 1.f;
+            sh[u] = scp ? shp[ci] : 0.f;
+        }
+    }
+};
+
+template <int CIN>
+struct PatchRegs {
+    static constexpr int N = CIN * PROWS * PSTRIDE, U = (N + SNT - 1) / SNT;
+    float v[U];
+    unsigned okmask;       // bit u: element u is inside the image (and a real patch column)
+};
+
+template <int CIN>
+__device__ __forceinline__ void fetch_patch(const float* __restrict__ x, int H, int W, int b, int ry, int cx,
+                                            const PatchPlan<CIN>& pl, PatchRegs<CIN>& r) {
+    const int iy0 = 4 * ry - 3, ix0 = 128 * cx - 3;
+    const float* base = x + ((size_t)b * CIN * H + iy0) * (ptrdiff_t)W + ix0;      // may point before the row: only valid taps are read
+    r.okmask = 0;
+#pragma unroll
+    for (int u = 0; u < PatchRegs<CIN>::U; ++u) {
+        const int j = pl.ji[u] >> 16, i = pl.ji[u] & 0xffff;
+        const bool ok = (unsigned)(iy0 + j) < (unsigned)H && (unsigned)(ix0 + i) < (unsigned)W;
+        r.okmask |= ok ? (1u << u) : 0u;
+        const float* a = ok ? base + pl.rel[u] : x;                                  // always a valid address
+        r.v[u] = *a;
+    }
+}
+
+template <int CIN>
+__device__ __forceinline__ void store_patch(float* patch, const PatchRegs<CIN>& r, const PatchPlan<CIN>& pl) {
+#pragma unroll
+    for (int u = 0; u < PatchRegs<CIN>::U; ++u) {
+        const int e = (int)threadIdx.x + u * SNT;
+        if (e < PatchRegs<CIN>::N) patch[e] = ((r.okmask >> u) & 1u) ? r.v[u] * pl.sc[u] + pl.sh[u] : 0.f;
+    }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(SNT) void stem_wgrad_kernel(StemParams p) {
     constexpr int KT = CIN * 56;                        // (ci, ky, kx8)
@@ -151,6 +205,147 @@ __global__ __launch_bounds__(SNT) void stem_wgrad_kernel(StemParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward: y[p][co] = sum_k patch[p][k] * w[co][k]  (M = pixels, N = 64 channels, K = Cin*56).
+// The packed weights stay resident in LDS as [k][64] for the whole persistent workgroup; the image patch is
+// double-buffered: the next tile's pixels are fetched into registers before the MFMAs of the current tile and
+// written to the other buffer after them, so one barrier per tile is all the synchronisation there is.
+// A wave owns 64 pixels x 32 channels (two 32x32 accumulators): per k-pair two patch reads and one weight read,
+// all at   per-lane base + immediate offset.   Epilogue: NHWC store and the BatchNorm statistics of bn1
+// (per-channel sum and sum of squares, one atomic pair per channel and wave at the very end).
+// ---------------------------------------------------------------------------------------------
+struct StemFwdParams {
+    const float* x;        // [B,Cin,H,W] planar
+    const float* w;        // [64][Cin][7][8] packed, kx = 7 column zero
+    float* y;              // [B,Ho,Wo,64]
+    float* stats;          // [2][64] or NULL
+    const float* sc;
+    const float* sh;
+    int B, H, W, Ho, Wo;
+    int row_pairs, col_tiles, tiles;
+    int dbg;               // timing experiments (DVS_STEM_DEBUG): 1 = no output stores, 2 = no patch re-staging, 4 = no MFMAs
+};
+
+template <int CIN>
+__global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
+    constexpr int K = CIN * 56, PN = CIN * PROWS * PSTRIDE;
+    static_assert(PatchRegs<CIN>::U <= 32, "okmask is 32 bits");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wl = smem;                    // [K][64]
+    float* patch0 = smem + K * 64;       // [2][CIN][9][136]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, h = lane >> 5;
+    for (int e = threadIdx.x; e < K * 64; e += SNT) {            // wl[k][co] = w[co][k]
+        const int co = e / K, k = e - co * K;
+        wl[k * 64 + co] = p.w[e];
+    }
+    PatchPlan<CIN> plan;
+    plan.init(p.H, p.W, p.sc, p.sh);
+    // per-lane bases: my two pixel rows of the patch (tile rows wm, columns tm*32 + r32) and my weight column
+    const int a_base0 = (2 * wm) * PSTRIDE + 2 * r32 + h, a_base1 = a_base0 + 64;
+    const int b_base = h * 64 + wn * 32 + r32;
+
+    float ssum = 0.f, ssq = 0.f;
+    int tile = blockIdx.x;
+    PatchRegs<CIN> pr;
+    if (tile < p.tiles) {
+        const int cx = tile % p.col_tiles, rest = tile / p.col_tiles;
+        fetch_patch<CIN>(p.x, p.H, p.W, rest / p.row_pairs, rest % p.row_pairs, cx, plan, pr);
+        store_patch<CIN>(patch0, pr, plan);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (; tile < p.tiles; tile += gridDim.x) {
+        const int cx = tile % p.col_tiles, rest = tile / p.col_tiles, ry = rest % p.row_pairs, b = rest / p.row_pairs;
+        const int nxt = tile + gridDim.x;
+        if (nxt < p.tiles && !(p.dbg & 2)) {
+            const int ncx = nxt % p.col_tiles, nrest = nxt / p.col_tiles;
+            fetch_patch<CIN>(p.x, p.H, p.W, nrest / p.row_pairs, nrest % p.row_pairs, ncx, plan, pr);   // in flight under the MFMAs
+        }
+        const float* patch = patch0 + cur * PN;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+        // k = 2s + h -> (ci, ky, kx = 2 (s & 3) + h): everything but h is an immediate.  Operands are fetched two
+        // k-steps ahead into a rotating register set and the order is pinned (sched_barrier): left to itself the
+        // compiler reuses one register set and waits for every ds_read right in front of its MFMA.
+        auto koff_of = [](int s) {
+            const int row = (2 * s) >> 3, ci = row / 7, ky = row - ci * 7, kx = (2 * s) & 7;
+            return (ci * PROWS + ky) * PSTRIDE + kx;
+        };
+        constexpr int KS = K / 2, AHEAD = 2;
+        float ra0[AHEAD + 1], ra1[AHEAD + 1], rb[AHEAD + 1];
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s) {
+            ra0[s] = patch[a_base0 + koff_of(s)];
+            ra1[s] = patch[a_base1 + koff_of(s)];
+            rb[s] = wl[b_base + 2 * s * 64];
+        }
+        if (!(p.dbg & 4))
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + AHEAD < KS) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                ra0[(s + AHEAD) % (AHEAD + 1)] = patch[a_base0 + koff_of(s + AHEAD)];
+                ra1[(s + AHEAD) % (AHEAD + 1)] = patch[a_base1 + koff_of(s + AHEAD)];
+                rb[(s + AHEAD) % (AHEAD + 1)] = wl[b_base + 2 * (s + AHEAD) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[s % (AHEAD + 1)], rb[s % (AHEAD + 1)], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[s % (AHEAD + 1)], rb[s % (AHEAD + 1)], acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // D map: column n = lane & 31 (channel), rows (i & 3) + 8 * (i >> 2) + 4 * h (pixel of the 32-pixel sub-tile)
+        const int oy = 2 * ry + wm, co = wn * 32 + r32;
+        if (oy < p.Ho && !(p.dbg & 1)) {
+            float* yrow = p.y + ((size_t)b * p.Ho + oy) * p.Wo * 64 + co;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c0 = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int ox0 = 64 * cx + c0, ox1 = ox0 + 32;
+                if (ox0 < p.Wo) {
+                    yrow[(size_t)ox0 * 64] = acc0[i];
+                    ssum += acc0[i];
+                    ssq += acc0[i] * acc0[i];
+                }
+                if (ox1 < p.Wo) {
+                    yrow[(size_t)ox1 * 64] = acc1[i];
+                    ssum += acc1[i];
+                    ssq += acc1[i] * acc1[i];
+                }
+            }
+        }
+        if (nxt < p.tiles && !(p.dbg & 2)) store_patch<CIN>(patch0 + (cur ^ 1) * PN, pr, plan);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (p.stats) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (h == 0) {
+            atomicAdd(p.stats + wn * 32 + r32, ssum);
+            atomicAdd(p.stats + 64 + wn * 32 + r32, ssq);
+        }
+    }
+}
+
+template <int CIN>
+void launch_fwd(StemFwdParams p, hipStream_t st) {
+    const size_t lds = ((size_t)CIN * 56 * 64 + 2 * CIN * PROWS * PSTRIDE) * sizeof(float);
+    auto kern = stem_fwd_kernel<CIN>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024 - 256) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int per_cu = (int)(160 * 1024 / lds);
+    int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    if (blocks > p.tiles) blocks = p.tiles;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(SNT), lds, st, p);
+}
+
 template <int CIN>
 void launch_wgrad(StemParams p, hipStream_t st) {
     const size_t lds = ((size_t)CIN * PROWS * PSTRIDE + TPX * 64) * sizeof(float);
@@ -193,6 +388,20 @@ void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, 
     p.dbg = dbg;
     if (s.Cin == 3) launch_wgrad<3>(p, st);
     else launch_wgrad<6>(p, st);
+}
+
+void stem_fwd(const float* x, const float* w, float* y, float* stats, const ConvShape& s, const float* sc,
+              const float* sh, hipStream_t st) {
+    StemFwdParams p{};
+    p.x = x; p.w = w; p.y = y; p.stats = stats; p.sc = sc; p.sh = sh;
+    p.B = s.B; p.H = s.H; p.W = s.W; p.Ho = s.Ho; p.Wo = s.Wo;
+    p.row_pairs = (s.Ho + 1) / 2;
+    p.col_tiles = (s.Wo + 63) / 64;
+    p.tiles = s.B * p.row_pairs * p.col_tiles;
+    static const int dbg = getenv("DVS_STEM_DEBUG") ? atoi(getenv("DVS_STEM_DEBUG")) : 0;
+    p.dbg = dbg;
+    if (s.Cin == 3) launch_fwd<3>(p, st);
+    else launch_fwd<6>(p, st);
 }
 
 }  // namespace dvsconv
