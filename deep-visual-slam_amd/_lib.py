@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
 
 class ConvFusion(C.Structure):
     _fields_ = [("x2", _vp), ("C1", C.c_int), ("in_scale", _vp), ("in_shift", _vp), ("in_relu", C.c_int),
-                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp)]
+                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp), ("stat_groups", C.c_int)]
 
 
 _SIGNATURES = {

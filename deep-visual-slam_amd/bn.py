@@ -12,37 +12,51 @@ from ._lib import check, ptr
 CL = torch.channels_last
 
 
-def _finalize(stats, count, bn):
-    C = stats.shape[1]
-    dev = stats.device
-    out = torch.empty(4, C, device=dev, dtype=torch.float32)      # scale, shift, mean, invstd
+def _finalize(stats, count, bn, out):
+    """stats [2][C] (sum, sum of squares) -> out [4][C] = scale, shift, mean, invstd; running statistics and
+    num_batches_tracked updated as nn.BatchNorm2d does in training mode."""
+    C = stats.shape[-1]
     train_stats = bn.training and bn.track_running_stats
     nbt = bn.num_batches_tracked if train_stats else None
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
-    check(_lib.lib().dvs_bn_finalize(ptr(stats), float(count), ptr(bn.weight), ptr(bn.bias),
+    check(_lib.lib().dvs_bn_finalize(stats.data_ptr(), float(count), ptr(bn.weight), ptr(bn.bias),
                                      ptr(bn.running_mean) if train_stats else None,
                                      ptr(bn.running_var) if train_stats else None,
                                      float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps),
                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), C,
                                      nbt.data_ptr() if nbt is not None else None, _lib.stream()), "dvs_bn_finalize")
+
+
+def _finalize_groups(stats, count, bn, groups):
+    """[G][4][C]; the groups are finalised in order, i.e. the running statistics see G successive updates -- what G
+    separate forward calls of the module would have done."""
+    C = stats.shape[-1]
+    out = torch.empty(groups, 4, C, device=stats.device, dtype=torch.float32)
+    st = stats.view(groups, 2, C)
+    for g in range(groups):
+        _finalize(st[g], count, bn, out[g])
     return out
 
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, res_gamma, res_beta, fin, res_fin, relu):
-        """z = act(bn(y) [+ residual | + bn_r(residual)]); fin / res_fin = [scale, shift, mean, invstd]."""
+    def forward(ctx, y, gamma, beta, residual, res_gamma, res_beta, fin, res_fin, relu, groups):
+        """z = act(bn(y) [+ residual | + bn_r(residual)]); fin / res_fin = [G][scale, shift, mean, invstd].
+        With G = 2 the first and the second half of the batch are normalised with their own statistics."""
         l = _lib.lib()
         B, C, H, W = y.shape
-        M = B * H * W
+        M = B * H * W // groups                       # rows per group
         z = torch.empty_like(y)
-        r_sc = res_fin[0].data_ptr() if res_fin is not None else None
-        r_sh = res_fin[1].data_ptr() if res_fin is not None else None
-        check(l.dvs_bn_apply_fwd(y.data_ptr(), fin[0].data_ptr(), fin[1].data_ptr(),
-                                 residual.data_ptr() if residual is not None else None, r_sc, r_sh, z.data_ptr(), M, C,
-                                 int(relu), _lib.stream()), "dvs_bn_apply_fwd")
-        ctx.relu = relu
+        st = _lib.stream()
+        for g in range(groups):
+            o = 4 * g * M * C                         # byte offset of the group's rows (batch is the outermost dim)
+            r_sc = res_fin[g, 0].data_ptr() if res_fin is not None else None
+            r_sh = res_fin[g, 1].data_ptr() if res_fin is not None else None
+            check(l.dvs_bn_apply_fwd(y.data_ptr() + o, fin[g, 0].data_ptr(), fin[g, 1].data_ptr(),
+                                     residual.data_ptr() + o if residual is not None else None, r_sc, r_sh,
+                                     z.data_ptr() + o, M, C, int(relu), st), "dvs_bn_apply_fwd")
+        ctx.relu, ctx.groups = relu, groups
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
         ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
         return z
@@ -51,45 +65,50 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dz):
         y, gamma, residual, res_gamma, fin, res_fin, z = ctx.saved_tensors
         l = _lib.lib()
+        G = ctx.groups
         B, C, H, W = y.shape
-        M = B * H * W
+        M = B * H * W // G
         dz = dz if dz.is_contiguous(memory_format=CL) else dz.contiguous(memory_format=CL)
         st = _lib.stream()
         need_du = ctx.relu or residual is not None
         du = torch.empty_like(y) if need_du else dz
-        sums = zeropool.zeros((2, C), y.device, pooled=gamma.grad is not None)
-        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C) // 4, device=y.device, dtype=torch.float32)
-        check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(), fin[2].data_ptr(),
-                                  fin[3].data_ptr(), du.data_ptr() if need_du else None, ptr(sums), ptr(ws), M, C, st),
-              "dvs_bn_bwd_reduce")
         dy = torch.empty_like(y)
+        pooled = gamma.grad is not None
+        sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
+        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C) // 4, device=y.device, dtype=torch.float32)
         g_par, b_par, rg_par, rb_par = ctx.affine
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
-        check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[2].data_ptr(), fin[3].data_ptr(), ptr(gamma), ptr(sums),
-                                 dy.data_ptr(), M, C, ptr(gs) if sunk else None, ptr(bs) if sunk else None, st),
-              "dvs_bn_bwd_apply")
-        if sunk:
-            d_gamma = d_beta = None
-        else:
-            d_gamma, d_beta = sums[1], sums[0]
-        d_res = d_rg = d_rb = None
+        ds_res = residual is not None and res_fin is not None
+        d_res = None
         if residual is not None:
-            if res_fin is None:
-                d_res = du
-            else:
-                rsums = zeropool.zeros((2, C), y.device, pooled=gamma.grad is not None)
-                check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[2].data_ptr(),
-                                          res_fin[3].data_ptr(), None, ptr(rsums), ptr(ws), M, C, st), "dvs_bn_bwd_reduce")
-                d_res = torch.empty_like(residual)
-                gs, bs = gradsink.target(rg_par), gradsink.target(rb_par)
-                sunk = gs is not None and bs is not None
-                check(l.dvs_bn_bwd_apply(du.data_ptr(), residual.data_ptr(), res_fin[2].data_ptr(), res_fin[3].data_ptr(),
-                                         ptr(res_gamma), ptr(rsums), d_res.data_ptr(), M, C, ptr(gs) if sunk else None,
-                                         ptr(bs) if sunk else None, st), "dvs_bn_bwd_apply")
-                if not sunk:
-                    d_rg, d_rb = rsums[1], rsums[0]
-        return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None
+            d_res = torch.empty_like(residual) if ds_res else du
+        if ds_res:
+            rsums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
+            rgs, rbs = gradsink.target(rg_par), gradsink.target(rb_par)
+            rsunk = rgs is not None and rbs is not None
+        for g in range(G):
+            o = 4 * g * M * C
+            check(l.dvs_bn_bwd_reduce(dz.data_ptr() + o, z.data_ptr() + o if ctx.relu else None, y.data_ptr() + o,
+                                      fin[g, 2].data_ptr(), fin[g, 3].data_ptr(), du.data_ptr() + o if need_du else None,
+                                      sums[g].data_ptr(), ptr(ws), M, C, st), "dvs_bn_bwd_reduce")
+            check(l.dvs_bn_bwd_apply(du.data_ptr() + o, y.data_ptr() + o, fin[g, 2].data_ptr(), fin[g, 3].data_ptr(),
+                                     ptr(gamma), sums[g].data_ptr(), dy.data_ptr() + o, M, C, ptr(gs) if sunk else None,
+                                     ptr(bs) if sunk else None, st), "dvs_bn_bwd_apply")
+            if ds_res:
+                check(l.dvs_bn_bwd_reduce(du.data_ptr() + o, None, residual.data_ptr() + o, res_fin[g, 2].data_ptr(),
+                                          res_fin[g, 3].data_ptr(), None, rsums[g].data_ptr(), ptr(ws), M, C, st),
+                      "dvs_bn_bwd_reduce")
+                check(l.dvs_bn_bwd_apply(du.data_ptr() + o, residual.data_ptr() + o, res_fin[g, 2].data_ptr(),
+                                         res_fin[g, 3].data_ptr(), ptr(res_gamma), rsums[g].data_ptr(),
+                                         d_res.data_ptr() + o, M, C, ptr(rgs) if rsunk else None,
+                                         ptr(rbs) if rsunk else None, st), "dvs_bn_bwd_apply")
+        d_gamma = d_beta = d_rg = d_rb = None
+        if not sunk:
+            d_gamma, d_beta = (sums[0, 1], sums[0, 0]) if G == 1 else (sums[:, 1].sum(0), sums[:, 0].sum(0))
+        if ds_res and not rsunk:
+            d_rg, d_rb = (rsums[0, 1], rsums[0, 0]) if G == 1 else (rsums[:, 1].sum(0), rsums[:, 0].sum(0))
+        return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None, None
 
 
 def supported_c(C, bn):
@@ -97,19 +116,23 @@ def supported_c(C, bn):
     return bn.training and bn.affine and C % 4 == 0 and (256 % (C // 4) == 0)
 
 
-def bn_act(y, bn, stats, relu=False, residual=None, res_bn=None, res_stats=None):
+def bn_act(y, bn, stats, relu=False, residual=None, res_bn=None, res_stats=None, groups=1):
     """act(bn(y) + residual') with batch statistics taken from `stats` (filled by the conv that produced y);
-    residual' = residual, or res_bn(residual) with its own `res_stats` (the BasicBlock downsample branch)."""
+    residual' = residual, or res_bn(residual) with its own `res_stats` (the BasicBlock downsample branch).
+    groups = 2: y holds two independent batches back to back (PoseNet's two frame pairs); each half is
+    normalised with its own statistics (stats = [2][2][C]) and the running statistics get both updates in order."""
     if not y.is_cuda:
         raise _lib.DvsError("bn_act: GPU tensors only; this package has no CPU path")
     B, C, H, W = y.shape
-    count = B * H * W
+    if B % groups:
+        raise _lib.DvsError("bn_act: batch %d does not split into %d groups" % (B, groups))
+    count = (B // groups) * H * W
     y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
-    fin = _finalize(stats, count, bn)
+    fin = _finalize_groups(stats, count, bn, groups)
     res_fin = None
     if residual is not None:
         residual = residual if residual.is_contiguous(memory_format=CL) else residual.contiguous(memory_format=CL)
         if res_bn is not None:
-            res_fin = _finalize(res_stats, count, res_bn)
+            res_fin = _finalize_groups(res_stats, count, res_bn, groups)
     return _BNAct.apply(y, bn.weight, bn.bias, residual, res_bn.weight if res_bn is not None else None,
-                        res_bn.bias if res_bn is not None else None, fin, res_fin, relu)
+                        res_bn.bias if res_bn is not None else None, fin, res_fin, relu, groups)

@@ -62,7 +62,7 @@ def _geometry(x, w_shape, x2, nchw_planar):
     return x, x2, B, Cin, H, W
 
 
-def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None):
+def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None, stat_groups=1):
     f = ConvFusion()
     if x2 is UPSAMPLE_ONLY:
         f.x2, f.C1 = x.data_ptr(), x.shape[1]      # C1 == Cin: the second source is never read
@@ -74,6 +74,7 @@ def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=Non
     f.act = ACT[act]
     if stats is not None:
         f.stats = ptr(stats)
+        f.stat_groups = int(stat_groups)
     return f
 
 
@@ -83,7 +84,7 @@ def _pack_planar_weight(weight):
 
 
 def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=None, x2=None, in_scale=None,
-                   in_shift=None, in_relu=False, nchw_planar=False, stats=None):
+                   in_shift=None, in_relu=False, nchw_planar=False, stats=None, stat_groups=1):
     """Raw forward launch (no autograd).  x: logical [B,Cin,H,W] (NHWC memory, or planar NCHW when
     nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1)."""
     if not (x.is_cuda and weight.is_cuda):
@@ -93,7 +94,7 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
     d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
     Ho, Wo = out_hw(H, W, d.kh, d.kw, stride, pad)
     y = torch.empty((B, d.Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
-    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats)
+    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats, stat_groups)
     check(_lib.lib().dvs_conv2d_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), C.byref(f),
                                     _lib.stream()), "dvs_conv2d_fwd")
     return y
@@ -166,9 +167,10 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, weight, bias, x2, opts):
         stride, pad, reflect, act, planar, scale, shift, want_stats = opts
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
-        stats = zeropool.zeros((2, weight.shape[0]), x.device) if want_stats else None
+        groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
+        stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
         y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
-                           nchw_planar=planar, stats=stats)
+                           nchw_planar=planar, stats=stats, stat_groups=max(groups, 1))
         ctx.opts = opts[:7]
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
@@ -301,4 +303,4 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     if x2 is None and upsample:
         x2 = UPSAMPLE_ONLY
     # want_stats: also return [2][Cout] per-channel sum / sum of squares of y (BatchNorm batch statistics)
-    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift, bool(want_stats)))
+    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift, int(want_stats)))

@@ -344,7 +344,7 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
 bool stem_shape(const ConvShape& s);
 void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, const float* sc, const float* sh,
                 hipStream_t st);
-void stem_fwd(const float* x, const float* w, float* y, float* stats, const ConvShape& s, const float* sc,
-              const float* sh, hipStream_t st);
+void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_groups, const ConvShape& s,
+              const float* sc, const float* sh, hipStream_t st);
 
 }  // namespace dvsconv

@@ -25,6 +25,7 @@ struct FwdParams {
     const float* bias;   // [Cout] or NULL
     float* y;            // [B,Ho,Wo,Cout]
     float* stats;        // [2][Cout] running sum / sum of squares of the raw output, or NULL
+    int stat_split;      // rows >= stat_split are counted into a second set stats + 2*Cout (0x7fffffff: one set)
     float* y2;           // data gradient of an upsample+concat conv: channels >= split_c1 go here ([B,H,W,Cout-C1]) ...
     int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
@@ -46,7 +47,7 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
         const int n = n0 + (wn * TN + tn) * 32 + ln;
         const bool n_ok = n < s.Cout;
         const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
-        float ssum = 0.f, ssq = 0.f;
+        float ssum = 0.f, ssq = 0.f, ssum1 = 0.f, ssq1 = 0.f;      // second pair: rows >= p.stat_split
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
@@ -55,8 +56,11 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
                 int m = mb + (i & 3) + 8 * (i >> 2);
                 float v = acc[tm][tn][i];
                 if (m < M && n_ok) {
-                    ssum += v;
-                    ssq += v * v;
+                    const bool second = m >= p.stat_split;
+                    ssum += second ? 0.f : v;
+                    ssq += second ? 0.f : v * v;
+                    ssum1 += second ? v : 0.f;
+                    ssq1 += second ? v * v : 0.f;
                     size_t pix = (size_t)m;
                     if (MODE == IN_DGRAD && rstep == 2) {       // parity-class row -> pixel of the full grid
                         int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
@@ -85,6 +89,14 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
             if (lh == 0 && n_ok) {
                 atomicAdd(p.stats + n, ssum);
                 atomicAdd(p.stats + s.Cout + n, ssq);
+            }
+            if (p.stat_split != 0x7fffffff) {
+                ssum1 += __shfl_xor(ssum1, 32, 64);
+                ssq1 += __shfl_xor(ssq1, 32, 64);
+                if (lh == 0 && n_ok) {
+                    atomicAdd(p.stats + 2 * s.Cout + n, ssum1);
+                    atomicAdd(p.stats + 3 * s.Cout + n, ssq1);
+                }
             }
         }
     }
@@ -419,6 +431,7 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
                 "dvs_conv2d_dgrad: tensors must have fewer than 2^31 elements (32-bit gather offsets)");
     FwdParams p{};
     p.x = dy; p.w = wt; p.y = dx;
+    p.stat_split = 0x7fffffff;
     ConvShape& s = p.s;
     int Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     s.B = d->B;
@@ -443,6 +456,7 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
                 "dvs_conv2d_fwd: bad descriptor");
     FwdParams p{};
     p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.stat_split = 0x7fffffff;
     ConvShape& s = p.s;
     s.B = d->B; s.H = d->H; s.W = d->W; s.Cin = d->Cin; s.Cout = d->Cout;
     s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
@@ -457,6 +471,9 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
         p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
         p.t.in_relu = f->in_relu; planar = f->nchw_planar;
         p.act = f->act; p.stats = f->stats;
+        DVS_REQUIRE(f->stat_groups >= 0 && f->stat_groups <= 2 && (f->stat_groups != 2 || (d->B % 2) == 0),
+                    "dvs_conv2d_fwd: stat_groups is 0, 1 or 2 (2 needs an even batch)");
+        p.stat_split = (f->stat_groups == 2) ? (d->B / 2) * s.Ho * s.Wo : 0x7fffffff;
         // C1 == Cin: upsample only (x2 is never read); otherwise the concat boundary must not split a 32-k stage
         DVS_REQUIRE(!(f->x2) || (f->C1 > 0 && (d->H & 1) == 0 && (d->W & 1) == 0 &&
                                  ((f->C1 == d->Cin && (f->C1 & 3) == 0) || (f->C1 < d->Cin && (f->C1 % BK) == 0))),
@@ -476,7 +493,7 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE) {
         dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
-        stem_fwd(x, w, y, p.stats, s, p.t.in_scale, p.t.in_shift, st);
+        stem_fwd(x, w, y, p.stats, f && f->stat_groups == 2 ? 2 : 1, s, p.t.in_scale, p.t.in_shift, st);
     } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st, dvs::SLOT_CONV_FWD);
         else launch_mode<IN_PLANAR, false>(p, st, dvs::SLOT_CONV_FWD);

@@ -218,7 +218,8 @@ struct StemFwdParams {
     const float* x;        // [B,Cin,H,W] planar
     const float* w;        // [64][Cin][7][8] packed, kx = 7 column zero
     float* y;              // [B,Ho,Wo,64]
-    float* stats;          // [2][64] or NULL
+    float* stats;          // [2][64] (or [2][2][64] with two batch groups) or NULL
+    int b_split;           // images >= b_split are counted into the second statistics set (B: one set)
     const float* sc;
     const float* sh;
     int B, H, W, Ho, Wo;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
     const int a_base0 = (2 * wm) * PSTRIDE + 2 * r32 + h, a_base1 = a_base0 + 64;
     const int b_base = h * 64 + wn * 32 + r32;
 
-    float ssum = 0.f, ssq = 0.f;
+    float ssum = 0.f, ssq = 0.f, ssum1 = 0.f, ssq1 = 0.f;
     int tile = blockIdx.x;
     PatchRegs<CIN> pr;
     if (tile < p.tiles) {
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
         }
         // D map: column n = lane & 31 (channel), rows (i & 3) + 8 * (i >> 2) + 4 * h (pixel of the 32-pixel sub-tile)
         const int oy = 2 * ry + wm, co = wn * 32 + r32;
+        float ts = 0.f, tq = 0.f;                       // this tile's statistics (one image, hence one group)
         if (oy < p.Ho && !(p.dbg & 1)) {
             float* yrow = p.y + ((size_t)b * p.Ho + oy) * p.Wo * 64 + co;
 #pragma unroll
@@ -307,15 +309,22 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
                 const int ox0 = 64 * cx + c0, ox1 = ox0 + 32;
                 if (ox0 < p.Wo) {
                     yrow[(size_t)ox0 * 64] = acc0[i];
-                    ssum += acc0[i];
-                    ssq += acc0[i] * acc0[i];
+                    ts += acc0[i];
+                    tq += acc0[i] * acc0[i];
                 }
                 if (ox1 < p.Wo) {
                     yrow[(size_t)ox1 * 64] = acc1[i];
-                    ssum += acc1[i];
-                    ssq += acc1[i] * acc1[i];
+                    ts += acc1[i];
+                    tq += acc1[i] * acc1[i];
                 }
             }
+        }
+        if (b >= p.b_split) {
+            ssum1 += ts;
+            ssq1 += tq;
+        } else {
+            ssum += ts;
+            ssq += tq;
         }
         if (nxt < p.tiles && !(p.dbg & 2)) store_patch<CIN>(patch0 + (cur ^ 1) * PN, pr, plan);
         __syncthreads();
@@ -327,6 +336,14 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
         if (h == 0) {
             atomicAdd(p.stats + wn * 32 + r32, ssum);
             atomicAdd(p.stats + 64 + wn * 32 + r32, ssq);
+        }
+        if (p.b_split < p.B) {
+            ssum1 += __shfl_xor(ssum1, 32, 64);
+            ssq1 += __shfl_xor(ssq1, 32, 64);
+            if (h == 0) {
+                atomicAdd(p.stats + 128 + wn * 32 + r32, ssum1);
+                atomicAdd(p.stats + 192 + wn * 32 + r32, ssq1);
+            }
         }
     }
 }
@@ -390,10 +407,11 @@ void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, 
     else launch_wgrad<6>(p, st);
 }
 
-void stem_fwd(const float* x, const float* w, float* y, float* stats, const ConvShape& s, const float* sc,
-              const float* sh, hipStream_t st) {
+void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_groups, const ConvShape& s,
+              const float* sc, const float* sh, hipStream_t st) {
     StemFwdParams p{};
     p.x = x; p.w = w; p.y = y; p.stats = stats; p.sc = sc; p.sh = sh;
+    p.b_split = stat_groups == 2 ? s.B / 2 : s.B;
     p.B = s.B; p.H = s.H; p.W = s.W; p.Ho = s.Ho; p.Wo = s.Wo;
     p.row_pairs = (s.Ho + 1) / 2;
     p.col_tiles = (s.Wo + 63) / 64;

@@ -67,6 +67,7 @@ class MonodepthTrainer:
         # the two networks' kernels fill each other's tails (a 450-workgroup conv on 256 CUs leaves 12 % of the chip
         # idle in its last round) and the many small launches of one hide behind the other's convolutions.
         # The two PoseNet passes stay in order on that one stream (they update the same BatchNorm running statistics).
+        self.pose_pairs_batched = bool(tr.get("pose_pairs_batched", os.environ.get("DVS_POSE_BATCHED", "1") != "0"))
         use_stream = tr.get("pose_stream", os.environ.get("DVS_POSE_STREAM", "1") != "0")
         self.pose_stream = (torch.cuda.Stream(device=self.device)
                             if use_stream and torch.device(self.device).type == "cuda" else None)
@@ -109,8 +110,17 @@ class MonodepthTrainer:
         """learner_new.py:107-129."""
         outputs = {}
         left, tgt, right = sample[("source_left", 0)], sample[("target_image", 0)], sample[("source_right", 0)]
-        axisangle_left, translation_left = self.pose_net(torch.cat([left, tgt], dim=1))
-        axisangle_right, translation_right = self.pose_net(torch.cat([tgt, right], dim=1))
+        if self.pose_pairs_batched and getattr(self.pose_net, "supports_pairs", False):
+            # both frame pairs in one PoseNet pass of batch 2B (per-pair BatchNorm statistics inside): half the launches,
+            # twice the rows per convolution
+            B = tgt.shape[0]
+            pair = torch.cat([torch.cat([left, tgt], dim=1), torch.cat([tgt, right], dim=1)], dim=0)
+            axisangle, translation = self.pose_net(pair, pairs=2)
+            axisangle_left, axisangle_right = axisangle[:B], axisangle[B:]
+            translation_left, translation_right = translation[:B], translation[B:]
+        else:
+            axisangle_left, translation_left = self.pose_net(torch.cat([left, tgt], dim=1))
+            axisangle_right, translation_right = self.pose_net(torch.cat([tgt, right], dim=1))
         outputs[("axisangle", 0, -1)] = axisangle_left
         outputs[("translation", 0, -1)] = translation_left
         outputs[("axisangle", 0, 1)] = axisangle_right

@@ -25,6 +25,26 @@ def _require_gpu(x, who):
     _lib.lib()  # the HIP library must be present even when a library conv is selected
 
 
+_batch_groups = 1
+
+
+class batch_groups:
+    """Context: the batch handed to conv_bn_act holds `n` independent sub-batches back to back (PoseNet evaluates
+    its two frame pairs as one batch of 2B); BatchNorm statistics, normalisation and running-stat updates are
+    kept per sub-batch, so the result equals n separate forward calls (vo/learner_new.py:113-114)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _batch_groups
+        self.prev, _batch_groups = _batch_groups, self.n
+
+    def __exit__(self, *exc):
+        global _batch_groups
+        _batch_groups = self.prev
+
+
 def conv_backend():
     return os.environ.get("DVS_CONV_BACKEND", "hip")
 
@@ -66,12 +86,15 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
     planar = planar_norm is not None
     fused = (conv_backend() == "hip" and _conv.supported(x, weight, None, planar) and _bn.supported_c(weight.shape[0], bn)
              and (res is None or (_conv.supported(residual, res[0]) and _bn.supported_c(res[0].shape[0], res[1]))))
+    G = _batch_groups
+    if G != 1 and not fused:
+        raise _lib.DvsError("batch_groups(%d) needs the fused HIP conv + BatchNorm path" % G)
     if fused:
-        y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=True)
+        y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G)
         if res is not None:
-            yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=True)
-            return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std)
-        return _bn.bn_act(y, bn, st, relu, residual=residual)
+            yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G)
+            return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G)
+        return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
     y = conv2d(x, weight, None, stride, padding, planar_norm=planar_norm)
     if res is not None:
         residual = batch_norm(conv2d(residual, res[0], None, res[2], 0), res[1])

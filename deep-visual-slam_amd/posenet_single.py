@@ -14,6 +14,7 @@ from .resnet_encoder import ResnetEncoder
 
 class PoseNet(nn.Module):
     """Pose estimation network with ResNet encoder and pose decoder"""
+    supports_pairs = True      # forward(x, pairs=2): two frame pairs in one pass (see forward)
 
     def __init__(self, num_layers=18, pretrained=True, num_input_images=2, stride=1):
         super().__init__()
@@ -32,8 +33,12 @@ class PoseNet(nn.Module):
         # weights live as [Cout][kh][kw][Cin] in memory (same logical shapes / state_dict)
         self.to(memory_format=torch.channels_last)
 
-    def forward(self, input_images):
-        feature = self.encoder(input_images)
+    def forward(self, input_images, pairs=1):
+        """pairs = 2 (an extension of the reference signature): `input_images` holds two batches back to back --
+        MonodepthTrainer's (left, target) and (target, right) pairs -- evaluated in one pass; BatchNorm treats each
+        half as its own batch, so outputs, gradients and running statistics equal two calls."""
+        with nn_ops.batch_groups(pairs):
+            feature = self.encoder(input_images)
         sq = self.convs["squeeze"]
         out = nn_ops.conv2d(feature[-1], sq.weight, sq.bias, 1, 0, act="relu")
         for i in range(3):

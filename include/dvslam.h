@@ -99,6 +99,9 @@ typedef struct {
     int act;                /* 0 none, 1 ReLU, 2 ELU(alpha=1), 3 sigmoid */
     float* stats;           /* non-NULL: [2][Cout], += per-channel sum and sum of squares of the raw
                                (pre-bias, pre-activation) output: BatchNorm batch statistics */
+    int stat_groups;        /* 0 / 1: one set of statistics; 2: stats is [2][2][Cout], the first and second half of
+                               the batch counted separately -- PoseNet runs its two frame pairs as one batch of 2B
+                               and the reference's two calls (vo/learner_new.py:113-114) normalise each pair alone */
 } dvs_conv_fusion;
 
 /* y [B,Ho,Wo,Cout] = act(conv(x, w) + bias); `f` may be NULL (no fusion). */

@@ -151,3 +151,31 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
     # parameter, sunk (the Functions return None) or not (conv1 of both encoders), used once or twice (PoseNet)
     assert set(fired) == set(flat.names), sorted(set(flat.names) - set(fired))
     assert all(v == 2 for v in fired.values()), {k: v for k, v in fired.items() if v != 2}
+
+
+def test_posenet_pairs_in_one_pass_equal_two_calls(gpu_device):
+    """PoseNet.forward(x, pairs=2) -- both frame pairs as one batch of 2B with per-pair BatchNorm statistics -- against
+    the reference's two calls (vo/learner_new.py:113-114): outputs, parameter gradients and the BatchNorm running
+    statistics (two momentum updates in call order) must agree."""
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    torch.manual_seed(21)
+    a = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
+    b = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
+    b.load_state_dict(a.state_dict())
+    B, H, W = 3, 96, 128
+    x1, x2 = torch.rand(B, 6, H, W, device=gpu_device), torch.rand(B, 6, H, W, device=gpu_device)
+    w = torch.randn(2 * B, 1, 1, 6, device=gpu_device)
+    aa1, t1 = a(x1)
+    aa2, t2 = a(x2)
+    (torch.cat([torch.cat([aa1, t1], -1), torch.cat([aa2, t2], -1)]) * w).sum().backward()
+    aab, tb = b(torch.cat([x1, x2]), pairs=2)
+    (torch.cat([aab, tb], -1) * w).sum().backward()
+    assert rel(aab, torch.cat([aa1, aa2])) < 1e-5 and rel(tb, torch.cat([t1, t2])) < 1e-5
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is not None:
+            assert rel(pb.grad, pa.grad) < 5e-3, n      # run-to-run jitter of the atomics is ~2e-3 at this size
+    for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if "num_batches_tracked" in n:
+            assert int(ba) == int(bb) == 2, n
+        elif ".fc." not in n:
+            assert rel(bb, ba) < 1e-5, n
