@@ -2,12 +2,31 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Timing experiments that switch kernel phases off (and therefore produce WRONG results) are compiled out of the
+// product: build with -DDVS_TIMING_EXPERIMENTS=1 to get the DVS_CONV_DEBUG_NOBARRIER / DVS_STEM_DEBUG switches that
+// DESIGN.md section 5 quotes.
+#ifndef DVS_TIMING_EXPERIMENTS
+#define DVS_TIMING_EXPERIMENTS 0
+#endif
+
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/dvslam.h"
 
 namespace dvs {
+
+inline int experiment_flags(const char* env) {
+#if DVS_TIMING_EXPERIMENTS
+    const char* e = getenv(env);
+    return e ? atoi(e) : 0;
+#else
+    (void)env;
+    return 0;
+#endif
+}
+
 
 // Per-thread last-error text (the C-ABI keeps no other thread-local state).
 char* err_buf();

@@ -337,7 +337,7 @@ void launch_cfg(const FwdParams& p0, hipStream_t st, int slot) {
             return;
         }
     }
-    static const int nobar = getenv("DVS_CONV_DEBUG_NOBARRIER") ? atoi(getenv("DVS_CONV_DEBUG_NOBARRIER")) : 0;
+    static const int nobar = dvs::experiment_flags("DVS_CONV_DEBUG_NOBARRIER");
     p.dbg_nobarrier = nobar;
     if (conv_nbuf() == 2) launch_buf<BM, BN, WM, WN, MODE, FOLD, 2>(p, st, slot);
     else launch_buf<BM, BN, WM, WN, MODE, FOLD, 1>(p, st, slot);

@@ -401,7 +401,7 @@ void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, 
     p.row_pairs = (s.Ho + 1) / 2;
     p.col_tiles = (s.Wo + 63) / 64;
     p.tiles = s.B * p.row_pairs * p.col_tiles;
-    static const int dbg = getenv("DVS_STEM_DEBUG") ? atoi(getenv("DVS_STEM_DEBUG")) : 0;
+    static const int dbg = dvs::experiment_flags("DVS_STEM_DEBUG");
     p.dbg = dbg;
     if (s.Cin == 3) launch_wgrad<3>(p, st);
     else launch_wgrad<6>(p, st);
@@ -416,7 +416,7 @@ void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_g
     p.row_pairs = (s.Ho + 1) / 2;
     p.col_tiles = (s.Wo + 63) / 64;
     p.tiles = s.B * p.row_pairs * p.col_tiles;
-    static const int dbg = getenv("DVS_STEM_DEBUG") ? atoi(getenv("DVS_STEM_DEBUG")) : 0;
+    static const int dbg = dvs::experiment_flags("DVS_STEM_DEBUG");
     p.dbg = dbg;
     if (s.Cin == 3) launch_fwd<3>(p, st);
     else launch_fwd<6>(p, st);

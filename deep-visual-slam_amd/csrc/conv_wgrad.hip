@@ -347,7 +347,7 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     prof.work(2.0 * M * p.s.Cout * k_real);
     if constexpr (!FOLD && MODE != IN_PLANAR) {
         static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
-        static const int dbg = getenv("DVS_CONV_DEBUG_NOBARRIER") ? atoi(getenv("DVS_CONV_DEBUG_NOBARRIER")) : 0;
+        static const int dbg = dvs::experiment_flags("DVS_CONV_DEBUG_NOBARRIER");
         p.dbg = dbg & 4;
         if (dma && p.t.dact == 0 && p.dbias == nullptr) {
             hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);

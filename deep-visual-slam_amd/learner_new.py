@@ -99,6 +99,10 @@ class MonodepthTrainer:
             with torch.cuda.stream(self.pose_stream):
                 poses = self._predict_poses(sample)
             outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
+            if getattr(self, "_timeline", False):                # tools/step_timeline.py
+                self._marks = {"pose_done": torch.cuda.Event(enable_timing=True), "depth_done": torch.cuda.Event(enable_timing=True)}
+                self._marks["pose_done"].record(self.pose_stream)
+                self._marks["depth_done"].record(main)
             main.wait_stream(self.pose_stream)
             for t in poses.values():
                 t.record_stream(main)                            # allocated on the pose stream, read by the chain
