@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     for (int t = 0; t < TN; ++t) for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float a = lane * 0.001f, b[TN];
     for (int t = 0; t < TN; ++t) b[t] = (lane + t) * 0.002f;
+    int iv[4] = {lane, lane + 1, lane + 2, lane + 3};
     for (int it = 0; it < iters; ++it) {
         const float* smi = sm + ((it * 36) & 1020);      // iteration-dependent base: the reads cannot be hoisted
         if (VAR == 0) {
@@ -52,6 +53,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 #pragma unroll
                 for (int t = 0; t < TN; ++t) bv[t] = bn[t];
             }
+        } else if (VAR == 4 || VAR == 5) {
+            // E: NV independent integer VALU instructions after every MFMA, same wave (does the wave's own VALU work
+            // issue in the shadow of its MFMA?)
+            constexpr int NV = VAR == 4 ? 4 : 12;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[t], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(iv[q % 4]) : "v"(lane), "v"(it));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         } else {
 #pragma unroll
             for (int s = 0; s < STEPS; s += 4) {
@@ -66,7 +83,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             }
         }
     }
-    float r = 0.f;
+    float r = (float)(iv[0] + iv[1] + iv[2] + iv[3]);
     for (int t = 0; t < TN; ++t) for (int i = 0; i < 16; ++i) r += acc[t][i];
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
@@ -97,6 +114,8 @@ int main() {
         run<1, 3>("B lds b32, read->use", bpc);
         run<2, 3>("C lds b32, prefetch 1 step", bpc);
         run<3, 3>("D lds b128, read->use", bpc);
+        run<4, 3>("E mfma + 4 VALU each", bpc);
+        run<5, 3>("E mfma + 12 VALU each", bpc);
         run<0, 4>("A mfma only", bpc);
         run<1, 4>("B lds b32, read->use", bpc);
         run<2, 4>("C lds b32, prefetch 1 step", bpc);
