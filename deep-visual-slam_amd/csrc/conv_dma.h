@@ -11,6 +11,14 @@
 // fetches) and again on the read: LDS slot s of row r holds k-chunk s ^ ((r >> 1) & 7), so the 16 rows a
 // ds_read_b128 lane group touches map to 16 distinct 16-byte slots of the 256-byte bank row.
 // Two LDS buffers, one barrier per stage: DMA(k+1) -> MFMA(k) -> s_waitcnt vmcnt(0) -> barrier.
+//
+// VALU budget.  On this chip the fp32 MFMA shares the SIMD's vector ALU: every VALU instruction a wave -- any wave
+// of the SIMD -- issues costs ~4.5 cycles of matrix throughput (tools/micro/mfma_feed.hip: 135 -> 105 -> 75 TF with
+// 0 / 4 / 12 VALU instructions per MFMA, the same at 1, 2 and 3 waves per SIMD), so address arithmetic is not hidden
+// behind the MFMAs, it is ADDED to them.  The gather offsets of a lane's rows depend on the tap only, so all of them
+// (rows x up to 9 taps) are computed once in the prologue and kept in registers; the K loop is unrolled over the taps
+// with a runtime loop over the 32-channel blocks inside, and a stage's issue is one add, one compare, one 64-bit
+// shift-add and two selects per DMA row: ~40 VALU per stage instead of ~175.
 // Used for NHWC / upsample+concat inputs and un-fused data gradients with Cin % 32 == 0 (the encoder's convs).
 #pragma once
 
@@ -49,25 +57,48 @@ __device__ __forceinline__ void mfma_stage_swz(const float* __restrict__ As, con
     }
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_INS = BM / 32, B_INS = BN / 32;          // DMA instructions per wave per stage (8 rows each)
+    constexpr int MAXTAP = 9;                                // 3x3 (or fewer: 1x1, the parity classes of a stride-2 dgrad)
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                // [2][BM][32]
     float* Bs = smem + 2 * BM * BK;                  // [2][BN][32]
 
     ConvShape s = p.s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS destinations stay scalar
     const int wm = wave / WN, wn = wave % WN;
-    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);      // see conv_fwd_kernel
-    const int bid_y = lg % p.g.y;
-    lg /= p.g.y;
-    const int bid_z = lg % p.g.z, bid_x = lg / p.g.z;
+    // N tile fastest, then M tile: the tiles that share an im2col slice are neighbours on one XCD (xcd_logical).
+    // The four parity classes of a stride-2 data gradient carry 1, 2, 2 and 4 taps: dealt round-robin in launch order
+    // (M tile fastest, class slowest, no remap) they balance across the XCDs; contiguous ranges measured 1.6x slower.
+    int bid_x, bid_y, bid_z;
+    if (p.g.z > 1) {
+        int lg = blockIdx.x;
+        bid_x = lg % p.g.x;
+        lg /= p.g.x;
+        bid_y = lg % p.g.y;
+        bid_z = lg / p.g.y;
+    } else {
+        int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y, p.g.remap);
+        bid_y = lg % p.g.y;
+        bid_x = lg / p.g.y;
+        bid_z = 0;
+    }
     const int m0 = bid_x * BM, n0 = bid_y * BN;
+    const float* const zero_page = p.zero_page;
 
-    int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0, kw_full = s.kw;
+    int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0;
     if (MODE == IN_DGRAD && s.stride == 2) {         // parity classes, see conv_fwd_kernel
         const int py = bid_z >> 1, px = bid_z & 1;
         oy0 = (py - s.pad) & 1;
@@ -83,84 +114,88 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     }
     const int M = s.B * Hr * Wr;
     if (m0 >= M) return;
+    const int ntap = s.kh * s.kw, nC = s.Cin / BK;   // taps of this launch / class, 32-channel blocks per tap
 
-    // my (row, slot) inside each 8-row DMA instruction, and the k-chunk that slot must receive
+    // ---- prologue: per (DMA row, tap) element offsets (NO_TAP: padding, row past the end) ----------------------
+    constexpr int NO_TAP = -2147483647 - 1;          // the concat source's offsets are rebased by -C1 and may be negative
     const int rsub = lane >> 3, slot = lane & 7;
-    int a_b[A_INS], a_iy[A_INS], a_ix[A_INS], a_q[A_INS];
-    bool a_ok[A_INS];
+    int toff[A_INS][MAXTAP];                         // into p.x   (IN_UPCAT: the half-resolution source)
+    int toff2[(MODE == IN_UPCAT) ? A_INS : 1][MAXTAP];   // into p.t.x2 (IN_UPCAT only)
+    int r_b[A_INS], r_y[A_INS], r_x[A_INS], r_q[A_INS];
+    bool r_ok[A_INS];
 #pragma unroll
     for (int j = 0; j < A_INS; ++j) {
         const int row = (wave * A_INS + j) * 8 + rsub;
-        a_q[j] = (slot ^ ((row >> 1) & 7)) << 2;                   // float offset of my k-chunk inside the stage
+        r_q[j] = (slot ^ ((row >> 1) & 7)) << 2;                     // float offset of my k-chunk inside the stage
         int m = m0 + row;
-        a_ok[j] = m < M;
+        r_ok[j] = m < M;
         m = min(m, M - 1);
-        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
-        int oy = rem / Wr, ox = rem - oy * Wr;
-        a_b[j] = b;
+        const int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
+        const int oy = rem / Wr, ox = rem - oy * Wr;
+        r_b[j] = b;
         if (MODE == IN_DGRAD) {
-            a_iy[j] = oy * rstep + oy0 + s.pad;
-            a_ix[j] = ox * rstep + ox0 + s.pad;
+            r_y[j] = oy * rstep + oy0 + s.pad;
+            r_x[j] = ox * rstep + ox0 + s.pad;
         } else {
-            a_iy[j] = oy * s.stride - s.pad;
-            a_ix[j] = ox * s.stride - s.pad;
+            r_y[j] = oy * s.stride - s.pad;
+            r_x[j] = ox * s.stride - s.pad;
+        }
+    }
+    int kc_tap[MAXTAP];                              // first weight column of each tap (uniform)
+#pragma unroll
+    for (int t = 0; t < MAXTAP; ++t) {
+        kc_tap[t] = 0;
+#pragma unroll
+        for (int j = 0; j < A_INS; ++j) {
+            toff[j][t] = NO_TAP;
+            if (MODE == IN_UPCAT) toff2[j][t] = NO_TAP;
+        }
+        if (t < ntap) {                                              // workgroup-uniform: unused taps cost nothing
+            const int tky = (t >= s.kw ? 1 : 0) + (t >= 2 * s.kw ? 1 : 0), tkx = t - tky * s.kw;   // kw <= 3, t < 9
+            kc_tap[t] = (MODE == IN_DGRAD) ? ((ky0 + rstep * tky) * p.s.kw + (kx0 + rstep * tkx)) * s.Cin : t * s.Cin;
+#pragma unroll
+            for (int j = 0; j < A_INS; ++j) {
+                bool ok = r_ok[j];
+                int off = 0, off2 = 0;
+                if (MODE == IN_DGRAD) dgrad_tap_setup(p.s, r_b[j], r_y[j], r_x[j], ky0 + rstep * tky, kx0 + rstep * tkx, ok, off);
+                else tap_setup<MODE>(s, p.t, r_b[j], r_y[j] + tky, r_x[j] + tkx, ok, off, off2);
+                toff[j][t] = ok ? off + r_q[j] : NO_TAP;
+                if (MODE == IN_UPCAT) toff2[j][t] = ok ? off2 + r_q[j] : NO_TAP;
+            }
         }
     }
     const float* b_ptr[B_INS];
-    int b_q[B_INS];
-    bool b_ok[B_INS];
 #pragma unroll
     for (int j = 0; j < B_INS; ++j) {
         const int row = (wave * B_INS + j) * 8 + rsub;
-        b_q[j] = (slot ^ ((row >> 1) & 7)) << 2;
-        int n = n0 + row;
-        b_ok[j] = n < s.Cout;
-        b_ptr[j] = p.w + (size_t)min(n, s.Cout - 1) * p.s.Ktot;
+        const int n = n0 + row;
+        // rows past Cout read the zero page every stage: their pointer is the page itself, advanced by 0 (see issue)
+        b_ptr[j] = (n < s.Cout) ? p.w + (size_t)n * p.s.Ktot + ((slot ^ ((row >> 1) & 7)) << 2) : nullptr;
     }
 
-    // the stage's (tap, channel base) is workgroup-uniform because Cin % 32 == 0
-    int kt_k = 0, ci0 = 0, tky = 0, tkx = 0, cur_tap = -1;
-    int t_off[A_INS], t_off2[A_INS];
-    bool t_ok[A_INS];
-    auto issue_stage = [&](int buf) {
-        const bool k_ok = kt_k < s.Ktot;
-        const int ky = ky0 + rstep * tky, kx = kx0 + rstep * tkx;
-        const int tap = ky * kw_full + kx;
-        if (tap != cur_tap) {
-            cur_tap = tap;
-#pragma unroll
-            for (int j = 0; j < A_INS; ++j) {
-                bool ok = a_ok[j];
-                if (MODE == IN_DGRAD) dgrad_tap_setup(p.s, a_b[j], a_iy[j], a_ix[j], ky, kx, ok, t_off[j]);
-                else tap_setup<MODE>(s, p.t, a_b[j], a_iy[j] + tky, a_ix[j] + tkx, ok, t_off[j], t_off2[j]);
-                t_ok[j] = ok;
-            }
+    // stage (tap T, channel block c) -> LDS buffer `buf`.  T is a compile-time constant: toff[.][T] is a register.
+    auto issue = [&](auto tc, int c, int buf) {
+        constexpr int T = decltype(tc)::value;
+        const int ci0 = c * BK;
+        const float* src = p.x;
+        int cadd = ci0;
+        bool use2 = false;
+        if (MODE == IN_UPCAT) {
+            use2 = ci0 >= p.t.C1;                                    // workgroup-uniform
+            src = use2 ? p.t.x2 : p.x;
         }
 #pragma unroll
         for (int j = 0; j < A_INS; ++j) {
-            const int ci = ci0 + a_q[j];
-            const float* gp;
-            if (MODE == IN_UPCAT && ci >= p.t.C1) gp = p.t.x2 + (t_off2[j] + ci);
-            else gp = p.x + (t_off[j] + ci);
-            if (!(t_ok[j] && k_ok)) gp = g_dvs_zero_page;
+            int off = toff[j][T];
+            if (MODE == IN_UPCAT) off = use2 ? toff2[j][T] : off;   // toff2 already carries the -C1 channel rebasing
+            const float* gp = off != NO_TAP ? src + (off + cadd) : zero_page;
             dma16(gp, As + (buf * BM + (wave * A_INS + j) * 8) * BK);
         }
-        const int kc = (MODE == IN_DGRAD) ? tap * s.Cin + ci0 : kt_k;        // column in the full weight row
+        const int kc = kc_tap[T] + ci0;
 #pragma unroll
         for (int j = 0; j < B_INS; ++j) {
-            const float* gp = b_ptr[j] + kc + b_q[j];
-            if (!(b_ok[j] && k_ok)) gp = g_dvs_zero_page;
+            const float* gp = b_ptr[j] ? b_ptr[j] + kc : zero_page;
             dma16(gp, Bs + (buf * BN + (wave * B_INS + j) * 8) * BK);
-        }
-        // advance to the next stage
-        kt_k += BK;
-        ci0 += BK;
-        if (ci0 >= s.Cin) {
-            ci0 = 0;
-            if (++tkx == s.kw) {
-                tkx = 0;
-                ++tky;
-            }
         }
     };
 
@@ -172,17 +207,31 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    const int KT = (s.Ktot + BK - 1) / BK;
-    issue_stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my LDS-DMA writes have landed ...
-    __syncthreads();                                       // ... and so have everyone else's
-#pragma unroll 1
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) issue_stage(buf ^ 1);          // lands in the other buffer while this one is multiplied
+    int buf = 0;
+    auto compute_and_sync = [&]() {
         mfma_stage_swz<TM, TN>(As + buf * BM * BK, Bs + buf * BN * BK, wm * TM * 32, wn * TN * 32, lane, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my LDS-DMA writes for the next stage have landed ...
+        __syncthreads();                                       // ... and so have everyone else's
+        buf ^= 1;
+    };
+    if (ntap > 0) {
+        issue(std::integral_constant<int, 0>{}, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    static_for<0, MAXTAP>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if (T < ntap) {                                         // workgroup-uniform
+#pragma unroll 1
+            for (int c = 0; c + 1 < nC; ++c) {
+                issue(tc, c + 1, buf ^ 1);                      // lands in the other buffer while this one is multiplied
+                compute_and_sync();
+            }
+            if constexpr (T + 1 < MAXTAP) {
+                if (T + 1 < ntap) issue(std::integral_constant<int, T + 1>{}, 0, buf ^ 1);
+            }
+            compute_and_sync();
+        }
+    });
     conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0);
 }

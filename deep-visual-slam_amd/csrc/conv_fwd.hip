@@ -15,6 +15,7 @@
 #include "conv_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace dvsconv;
@@ -29,6 +30,7 @@ struct FwdParams {
     float* y2;           // data gradient of an upsample+concat conv: channels >= split_c1 go here ([B,H,W,Cout-C1]) ...
     int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
+    const float* zero_page;   // 16 bytes of zeros: what the LDS-DMA kernel fetches for padding / tail lanes
     Grid3 g;             // logical grid: M tiles, N tiles, parity classes (launched 1-D, see xcd_logical)
     ConvShape s;
     InXform t;
@@ -120,10 +122,22 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     // N tile fastest, then parity class, then M tile: the tiles that share an im2col slice are neighbours
-    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);
-    const int bid_y = lg % p.g.y;
-    lg /= p.g.y;
-    const int bid_z = lg % p.g.z, bid_x = lg / p.g.z;
+    // N tile fastest, then M tile: the tiles that share an im2col slice are neighbours on one XCD (xcd_logical).
+    // The four parity classes of a stride-2 data gradient carry 1, 2, 2 and 4 taps: dealt round-robin in launch order
+    // (M tile fastest, class slowest, no remap) they balance across the XCDs; contiguous ranges measured 1.6x slower.
+    int bid_x, bid_y, bid_z;
+    if (p.g.z > 1) {
+        int lg = blockIdx.x;
+        bid_x = lg % p.g.x;
+        lg /= p.g.x;
+        bid_y = lg % p.g.y;
+        bid_z = lg / p.g.y;
+    } else {
+        int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y, p.g.remap);
+        bid_y = lg % p.g.y;
+        bid_x = lg / p.g.y;
+        bid_z = 0;
+    }
     const int m0 = bid_x * BM, n0 = bid_y * BN;
     const int c4 = (tid & 7) * 4, r0 = tid >> 3;            // my k-offset inside a stage, my first row
 
@@ -295,7 +309,7 @@ void launch_buf(const FwdParams& p, hipStream_t st, int slot);
 template <int MODE, bool FOLD>
 bool dma_eligible(const FwdParams& p) {
     static const bool enabled = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
-    if (!enabled || FOLD || MODE == IN_PLANAR || (p.s.Cin % BK) != 0) return false;
+    if (!enabled || FOLD || MODE == IN_PLANAR || (p.s.Cin % BK) != 0 || p.s.kh > 3 || p.s.kw > 3) return false;
     if (MODE == IN_DGRAD) return p.t.dact == 0 && p.s.pad_mode == PAD_ZERO && p.split_c1 == 0;
     return true;
 }
@@ -325,6 +339,12 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     prof.work(2.0 * M * p.s.Cout * (double)p.s.Ktot * eff);
     FwdParams q = p;
     q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
+    static const float* zp = [] {
+        void* d = nullptr;
+        (void)hipGetSymbolAddress(&d, HIP_SYMBOL(g_dvs_zero_page));
+        return static_cast<const float*>(d);
+    }();
+    q.zero_page = zp;
     hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(NT), lds, st, q);
 }
 
