@@ -203,6 +203,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
 // the channel dimension), hence no swizzle is needed here.
 __device__ __attribute__((aligned(16))) float g_dvs_zero_page_w[4] = {0.f, 0.f, 0.f, 0.f};
 
+// VALU diet (the fp32 MFMA shares the vector ALU, see conv_dma.h): a lane's tap is fixed for the whole kernel and
+// only the pixel advances, so everything about a PIXEL -- image, window origin, base offset: two divisions -- is
+// computed once per pixel by one thread into a small LDS ring (256 pixels per half, refilled every 8 stages), and a
+// stage's per-row work is a ds_read_b64 plus two bounds compares, one add, one 64-bit shift-add and two selects
+// (~10 VALU instead of ~40 of incremental coordinate updates + padding arithmetic).  Zero padding, NHWC input only:
+// the encoder convolutions, which are all this kernel serves.
+constexpr int PT = 256;          // pixels per half of the pixel ring (8 stages)
+
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -210,11 +218,14 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     constexpr int DV = BM / 4, XV = BN / 4;                  // 16-byte slots per pixel row
     constexpr int D_RPI = 64 / DV, X_RPI = 64 / XV;          // pixel rows per instruction
     static_assert(WM * WN == 4 && DV <= 64 && XV <= 64, "tile");
+    static_assert(MODE == IN_NHWC, "plain NHWC input");
     __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
     __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+    __shared__ int2 ptab[2][PT];                             // .x: offset of the window origin, .y: y0 << 16 | x0 & 0xffff
 
     const ConvShape& s = p.s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int M = s.B * s.Ho * s.Wo;
     // Cout tile fastest, then (tap,ci) tile, then pixel split: the tiles of one split read the same pixels
@@ -225,55 +236,58 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     const int co0 = bid_x * BM, k0 = bid_y * BN;
     const int m_begin = bid_z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
 
-    const int d_c = (lane % DV) * 4, d_r = lane / DV;       // my channel slice / pixel row inside an instruction
-    const int co = co0 + d_c;
-    const bool co_ok = co < s.Cout;
+    // one pixel of the ring per thread: (b, oy, ox) -> window origin (y0, x0) and its element offset
+    auto fill_ring = [&](int half, int m_first) {
+        const int m = m_first + tid;
+        int2 e;
+        e.x = 0;
+        e.y = (int)0x80008000u;                              // y0 = x0 = -32768: never inside the image
+        if (m < m_end) {
+            const int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+            const int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+            const int y0 = oy * s.stride - s.pad, x0 = ox * s.stride - s.pad;
+            e.x = ((b * s.H + y0) * s.W + x0) * s.Cin;
+            e.y = (int)(((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu));
+        }
+        ptab[half][tid] = e;
+    };
+
+    // dY rows: pointer of my 16-byte slice in the first stage, advanced by BP rows per stage
+    const int d_c = (lane % DV) * 4, d_r = lane / DV;
+    const bool co_ok = co0 + d_c < s.Cout;
+    const float* d_ptr[D_INS];
+    int d_m[D_INS];
+#pragma unroll
+    for (int j = 0; j < D_INS; ++j) {
+        d_m[j] = m_begin + (wave * D_INS + j) * D_RPI + d_r;
+        d_ptr[j] = p.dy + (size_t)d_m[j] * s.Cout + min(co0 + d_c, s.Cout - 4);
+    }
+    // X rows: my tap and channel slice are fixed; the pixel comes from the ring
     const int x_c = (lane % XV) * 4, x_r = lane / XV;
     const int k = k0 + x_c;
     const bool k_ok = k < s.Ktot;
     const int kc = min(k, s.Ktot - 4), tap = kc / s.Cin, ci = kc - tap * s.Cin, ky = tap / s.kw, kx = tap - ky * s.kw;
+    const int lane_off = (ky * s.W + kx) * s.Cin + ci;
+    const size_t d_step = (size_t)BP * s.Cout;
 
-    // pixel coordinates of my X rows, advanced incrementally by BP pixels per stage (no divisions in the loop)
-    int x_b[X_INS], x_oy[X_INS], x_ox[X_INS];
-#pragma unroll
-    for (int j = 0; j < X_INS; ++j) {
-        int m = min(m_begin + (wave * X_INS + j) * X_RPI + x_r, M - 1);
-        x_b[j] = m / (s.Ho * s.Wo);
-        int rem = m - x_b[j] * (s.Ho * s.Wo);
-        x_oy[j] = rem / s.Wo;
-        x_ox[j] = rem - x_oy[j] * s.Wo;
-    }
     auto issue_stage = [&](int mb, int buf) {
+        const int ring = (mb - m_begin) & (2 * PT - 1);               // position of the stage's first pixel in the ring
 #pragma unroll
         for (int j = 0; j < D_INS; ++j) {
-            const int row = (wave * D_INS + j) * D_RPI + d_r, m = mb + row;
-            const float* gp = p.dy + (size_t)min(m, M - 1) * s.Cout + min(co, s.Cout - 4);
-            if (!(m < m_end && co_ok)) gp = g_dvs_zero_page_w;
+            const float* gp = (d_m[j] < m_end && co_ok) ? d_ptr[j] : g_dvs_zero_page_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)&Ds[buf][(wave * D_INS + j) * D_RPI][0],
                                              16, 0, 0);
+            d_m[j] += BP;
+            d_ptr[j] += d_step;
         }
 #pragma unroll
         for (int j = 0; j < X_INS; ++j) {
-            const int row = (wave * X_INS + j) * X_RPI + x_r;
-            const int m = mb + row;
-            bool ok = m < m_end && k_ok;
-            const int b = min(x_b[j], s.B - 1), oy = x_oy[j], ox = x_ox[j];
-            int off, off2;
-            tap_setup<MODE>(s, p.t, b, oy * s.stride - s.pad + ky, ox * s.stride - s.pad + kx, ok, off, off2);
-            // next stage: BP pixels further along the flattened (b, oy, ox) index
-            x_ox[j] += BP;
-            while (x_ox[j] >= s.Wo) {
-                x_ox[j] -= s.Wo;
-                if (++x_oy[j] == s.Ho) {
-                    x_oy[j] = 0;
-                    ++x_b[j];
-                }
-            }
-            const float* gp;
-            if (MODE == IN_UPCAT && ci >= p.t.C1) gp = p.t.x2 + (off2 + ci);
-            else gp = p.x + (off + ci);
-            if (!ok) gp = g_dvs_zero_page_w;
+            const int slot = ring + (wave * X_INS + j) * X_RPI + x_r;
+            const int2 e = (&ptab[0][0])[slot];
+            const int y = (e.y >> 16) + ky, x = (int)(short)(e.y & 0xffff) + kx;
+            const bool ok = k_ok && (unsigned)y < (unsigned)s.H && (unsigned)x < (unsigned)s.W;
+            const float* gp = ok ? p.x + (e.x + lane_off) : g_dvs_zero_page_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                              (__attribute__((address_space(3))) void*)&Xs[buf][(wave * X_INS + j) * X_RPI][0],
                                              16, 0, 0);
@@ -290,12 +304,18 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
 
     const int r = lane & 31, h = lane >> 5;
     const int a_col = wm * TM * 32 + r, b_col = wn * TN * 32 + r;
+    fill_ring(0, m_begin);
+    fill_ring(1, m_begin + PT);
+    __syncthreads();
     if (m_begin < m_end) issue_stage(m_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int buf = 0;
+    int buf = 0, stage = 0;
 #pragma unroll 1
-    for (int mb = m_begin; mb < m_end; mb += BP) {
+    for (int mb = m_begin; mb < m_end; mb += BP, ++stage) {
+        // refill the half of the ring that the stages issued from now on no longer touch: at stage 8q (q >= 1) the
+        // next issue reads pixels of stage 8q+1, which live in half q & 1; half (q-1) & 1 ... is the one to reuse
+        if ((stage & 7) == 0 && stage > 0) fill_ring(((stage >> 3) + 1) & 1, m_begin + ((stage >> 3) + 1) * PT);
         if (!p.dbg && mb + BP < m_end) issue_stage(mb + BP, buf ^ 1);
 #pragma unroll
         for (int t = 0; t < BP / 2; ++t) {
@@ -349,8 +369,9 @@ void launch_cfg(WgradParams p, hipStream_t st) {
         static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
         static const int dbg = dvs::experiment_flags("DVS_CONV_DEBUG_NOBARRIER");
         p.dbg = dbg & 4;
-        if (dma && p.t.dact == 0 && p.dbias == nullptr) {
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, MODE>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+        if (dma && MODE == IN_NHWC && p.s.pad_mode == PAD_ZERO && p.t.dact == 0 && p.dbias == nullptr && p.s.H < 32768 &&
+            p.s.W < 32768) {
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
             return;
         }
     }
