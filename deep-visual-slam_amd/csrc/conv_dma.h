@@ -233,5 +233,10 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
             compute_and_sync();
         }
     });
-    conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0);
+    int* rowtab = nullptr;
+    if (MODE == IN_DGRAD && rstep == 2) {
+        rowtab = reinterpret_cast<int*>(smem);
+        fill_row_table<BM>(p, s, rowtab, m0, M, Hr, Wr, rstep, oy0, ox0);
+    }
+    conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0, rowtab, BM);
 }

@@ -39,9 +39,37 @@ struct FwdParams {
 
 // Epilogue shared by the register-staged and the LDS-DMA kernels: bias, activation, BatchNorm statistics,
 // the data-gradient row mappings (stride-2 parity classes, upsample+concat split) and the NHWC store.
+// Row -> output pixel for the data-gradient modes (stride-2 parity classes, upsample+concat split).  The mapping
+// needs two integer divisions per ROW; done per output ELEMENT in the epilogue loop it was ~4500 VALU instructions
+// per wave -- more than the whole K loop of the thin decoder layers -- so one thread per row computes it once into
+// LDS (the tiles are free after the last stage) and the epilogue reads it back.
+template <int BM>
+__device__ __forceinline__ void fill_row_table(const FwdParams& p, const ConvShape& s, int* tab, int m0, int M, int Hr, int Wr,
+                                               int rstep, int oy0, int ox0) {
+    const int r = threadIdx.x;
+    if (r < BM) {
+        const int m = min(m0 + r, M - 1);
+        int pix = m, cp = 0;
+        if (rstep == 2) {                                // parity-class row -> pixel of the full grid
+            const int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
+            const int oy = rem / Wr, ox = rem - oy * Wr;
+            pix = (b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
+        }
+        if (p.split_c1 > 0) {                            // pixel of the half-resolution tensor that receives the 2x2 sum
+            const int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
+            const int yy = rem / s.Wo, xx = rem - yy * s.Wo;
+            cp = (b * (s.Ho >> 1) + (yy >> 1)) * (s.Wo >> 1) + (xx >> 1);
+        }
+        tab[r] = pix;
+        tab[BM + r] = cp;
+    }
+    __syncthreads();
+}
+
 template <int TM, int TN, int MODE>
 __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0, int n0,
-                                              int wm, int wn, int lane, int M, int Hr, int Wr, int rstep, int oy0, int ox0) {
+                                              int wm, int wn, int lane, int M, int Hr, int Wr, int rstep, int oy0, int ox0,
+                                              const int* rowtab, int bm) {
     // epilogue.  C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int ln = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -64,17 +92,11 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
                     ssum1 += second ? v : 0.f;
                     ssq1 += second ? v * v : 0.f;
                     size_t pix = (size_t)m;
-                    if (MODE == IN_DGRAD && rstep == 2) {       // parity-class row -> pixel of the full grid
-                        int b = m / (Hr * Wr), rem = m - b * (Hr * Wr);
-                        int oy = rem / Wr, ox = rem - oy * Wr;
-                        pix = ((size_t)b * s.Ho + (oy * 2 + oy0)) * s.Wo + (ox * 2 + ox0);
-                    }
+                    if (MODE == IN_DGRAD && rowtab) pix = (size_t)rowtab[m - m0];
                     if (MODE == IN_DGRAD && p.split_c1 > 0) {
                         // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
                         if (n < p.split_c1) {
-                            int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
-                            int yy = rem / s.Wo, xx = rem - yy * s.Wo;
-                            size_t cp = ((size_t)b * (s.Ho >> 1) + (yy >> 1)) * (s.Wo >> 1) + (xx >> 1);
+                            const size_t cp = (size_t)rowtab[bm + m - m0];
                             atomicAdd(p.y + cp * p.split_c1 + n, v);
                         } else {
                             p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
@@ -290,7 +312,12 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
         if (!(p.dbg_nobarrier & 1)) __syncthreads();
     }
 
-    conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0);
+    int* rowtab = nullptr;
+    if (MODE == IN_DGRAD && (rstep == 2 || p.split_c1 > 0)) {
+        rowtab = reinterpret_cast<int*>(smem);
+        fill_row_table<BM>(p, s, rowtab, m0, M, Hr, Wr, rstep, oy0, ox0);
+    }
+    conv_epilogue<TM, TN, MODE>(p, s, acc, m0, n0, wm, wn, lane, M, Hr, Wr, rstep, oy0, ox0, rowtab, BM);
 }
 
 int conv_nbuf() {
