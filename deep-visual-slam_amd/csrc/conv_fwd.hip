@@ -96,8 +96,13 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
                     if (MODE == IN_DGRAD && p.split_c1 > 0) {
                         // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
                         if (n < p.split_c1) {
-                            const size_t cp = (size_t)rowtab[bm + m - m0];
-                            atomicAdd(p.y + cp * p.split_c1 + n, v);
+                            // rows m (even) and m + 1 are horizontal neighbours of one 2x2 block (Wo, the tile origin and
+                            // the register pairing i, i+1 are all even): add them in registers, one atomic per pair
+                            if ((i & 1) == 0) {
+                                const float pair = (m + 1 < M) ? acc[tm][tn][i + 1] : 0.f;
+                                const size_t cp = (size_t)rowtab[bm + m - m0];
+                                atomicAdd(p.y + cp * p.split_c1 + n, v + pair);
+                            }
                         } else {
                             p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
                         }
