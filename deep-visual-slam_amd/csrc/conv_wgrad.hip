@@ -40,6 +40,16 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
     __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
     __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+    // Gather-offset ring (all modes but the planar stem): the two divisions that turn a pixel index into (b, oy, ox)
+    // and the padding / reflection / upsample arithmetic of a tap depend on the PIXEL and the TAP only, yet every
+    // one of the Cin/4 lanes that fetch a slice of that pixel used to redo them every stage (~100 VALU per 16-byte
+    // vector; the fp32 MFMA shares the vector ALU, so that was most of the kernel).  Now each (pixel, tap) offset is
+    // computed once, by one thread, into LDS: 2 halves x RP pixels x up to 9 taps, refilled every RP/BP stages.
+    constexpr int RP = 64, RTAPS = 9;
+    constexpr bool RING = MODE != IN_PLANAR;
+    constexpr int ROFF = (MODE == IN_UPCAT) ? 2 : 1;        // IN_UPCAT: one offset per source
+    __shared__ int rtab[RING ? 2 * RP * RTAPS * ROFF : 1];
+    constexpr int NO_TAP = -2147483647 - 1;
     float* sBias = &Ds[0][0][0];    // reused after the pixel loop (the loop ends on a barrier)
 
     const ConvShape& s = p.s;
@@ -82,6 +92,76 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
         fsc = *reinterpret_cast<const f32x4*>(p.t.in_scale + ci);
         fsh = *reinterpret_cast<const f32x4*>(p.t.in_shift + ci);
     }
+    // ---- ring fill: thread -> (slot = tid % RP, taps tid / RP, + NT/RP, ...) of one half --------------------------
+    const int ntap = (MODE == IN_PLANAR) ? 0 : s.kh * s.kw;
+    const bool ring_ok = RING && ntap <= RTAPS;              // otherwise the per-vector path below
+    int f_b = 0, f_oy = 0, f_ox = 0, f_m = 0;               // my ring pixel: slot tid % RP of the next block of RP pixels
+    auto ring_seek = [&](int m) {                           // (divisions: once per kernel)
+        f_m = m;
+        const int mc = min(m, M - 1);
+        f_b = mc / (s.Ho * s.Wo);
+        const int rem = mc - f_b * (s.Ho * s.Wo);
+        f_oy = rem / s.Wo;
+        f_ox = rem - f_oy * s.Wo;
+    };
+    auto ring_fill = [&](int half) {                        // writes the entries of pixel f_m, then advances it
+        if (RING) {
+            const int slot = tid % RP;
+            for (int t = tid / RP; t < ntap; t += NT / RP) {
+                const int tky = t / s.kw, tkx = t - tky * s.kw;
+                bool ok = f_m < m_end;
+                int off = 0, off2 = 0;
+                tap_setup<MODE == IN_PLANAR ? IN_NHWC : MODE>(s, p.t, f_b, f_oy * s.stride - s.pad + tky,
+                                                              f_ox * s.stride - s.pad + tkx, ok, off, off2);
+                int* e = rtab + ((half * RP + slot) * RTAPS + t) * ROFF;
+                e[0] = ok ? off : NO_TAP;
+                if (ROFF == 2) e[1] = ok ? off2 : NO_TAP;
+            }
+            f_m += RP;                                       // the halves are filled alternately: next block of RP pixels
+            f_ox += RP;
+            while (f_ox >= s.Wo) {
+                f_ox -= s.Wo;
+                if (++f_oy == s.Ho) {
+                    f_oy = 0;
+                    f_b = min(f_b + 1, s.B - 1);
+                }
+            }
+        }
+    };
+    const int my_tap = ky * s.kw + kx;
+    const bool src2 = MODE == IN_UPCAT && ci >= p.t.C1;     // my channel slice lives in the second (skip) source
+    const float* const x_src = src2 ? p.t.x2 : p.x;
+    // dY rows: pointer of my slice in the first stage, advanced by BP rows per stage
+    const float* d_ptr[D_VECS];
+    int d_m[D_VECS];
+#pragma unroll
+    for (int j = 0; j < D_VECS; ++j) {
+        d_m[j] = m_begin + d_p0 + (NT / DV) * j;
+        d_ptr[j] = p.dy + (size_t)d_m[j] * s.Cout + min(co, s.Cout - 4);
+    }
+    const ptrdiff_t aux_delta = p.t.dact ? (p.t.aux - p.dy) : 0;
+    const size_t d_step = (size_t)BP * s.Cout;
+    auto load_stage_ring = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < D_VECS; ++j) {
+            rd_ok[j] = d_m[j] < m_end && co_ok;
+            const float* a = rd_ok[j] ? d_ptr[j] : p.dy;            // always a valid address, no branch around the load
+            rd[j] = *reinterpret_cast<const f32x4*>(a);
+            if (p.t.dact) rdy[j] = *reinterpret_cast<const f32x4*>(a + aux_delta);
+            d_m[j] += BP;
+            d_ptr[j] += d_step;
+        }
+        const int ring = (mb - m_begin) & (2 * RP - 1);
+#pragma unroll
+        for (int j = 0; j < X_VECS; ++j) {
+            const int slot = ring + x_p0 + (NT / XV) * j;
+            const int off = rtab[(slot * RTAPS + my_tap) * ROFF + (src2 ? 1 : 0)];
+            const bool ok = k_ok && off != NO_TAP;
+            const float* a = ok ? x_src + (off + ci) : p.x;
+            rx[j] = *reinterpret_cast<const f32x4*>(a);
+            rx_ok[j] = ok;
+        }
+    };
     auto load_stage = [&](int mb) {
 #pragma unroll
         for (int j = 0; j < D_VECS; ++j) {
@@ -143,16 +223,33 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
 
     const int r = lane & 31, h = lane >> 5;
     const int a_col = wm * TM * 32 + r, b_col = wn * TN * 32 + r;
+    if (ring_ok) {
+        ring_seek(m_begin + tid % RP);
+        ring_fill(0);                                         // pixels [0, RP) of my range
+        ring_fill(1);                                         // pixels [RP, 2 RP)
+        __syncthreads();
+    }
     if (m_begin < m_end) {
-        load_stage(m_begin);
+        if (ring_ok) load_stage_ring(m_begin);
+        else load_stage(m_begin);
         store_stage(0);
     }
     __syncthreads();
-    int buf = 0;
+    int buf = 0, stage = 0;
+    constexpr int SPH = RP / BP;                              // stages per ring half
 #pragma unroll 1
-    for (int mb = m_begin; mb < m_end; mb += BP) {
+    for (int mb = m_begin; mb < m_end; mb += BP, ++stage) {
         const bool more = mb + BP < m_end;
-        if (more) load_stage(mb + BP);
+        // at stage q*SPH (q >= 1) the loads issued from now on read half q & 1 (and later); refill the other one with
+        // the pixels of half-index q + 1
+        if (ring_ok && stage > 0 && (stage % SPH) == 0) {
+            if (((stage / SPH) & 1) == 0) ring_fill(1);       // q even: half 1 is free  (it held q - 1)
+            else ring_fill(0);
+        }
+        if (more) {
+            if (ring_ok) load_stage_ring(mb + BP);
+            else load_stage(mb + BP);
+        }
 #pragma unroll
         for (int t = 0; t < BP / 2; ++t) {
             float a[TM], b[TN];
