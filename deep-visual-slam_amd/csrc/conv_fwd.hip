@@ -66,33 +66,41 @@ __device__ __forceinline__ void fill_row_table(const FwdParams& p, const ConvSha
     __syncthreads();
 }
 
-template <int TM, int TN, int MODE>
-__device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0, int n0,
-                                              int wm, int wn, int lane, int M, int Hr, int Wr, int rstep, int oy0, int ox0,
-                                              const int* rowtab, int bm) {
-    // epilogue.  C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+// Epilogue body, specialised at compile time on what a launch needs (the fp32 MFMA shares the vector ALU, so the
+// ~10 VALU instructions per output element that a do-everything epilogue spends on statistics selects, activation
+// dispatch and 64-bit index arithmetic it does not need are paid in matrix throughput):
+//   STATS 0: none   1: whole tile in one statistics group   2: tile straddles the group boundary (per-element test)
+//   ACT   false: plain store (no bias, no activation)       true: + bias, runtime activation
+template <int TM, int TN, int MODE, int STATS, bool ACT>
+__device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0,
+                                                   int n0, int wm, int wn, int lane, int M, const int* rowtab, int bm) {
+    // C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int ln = lane & 31, lh = lane >> 5;
+    const bool tile_second = m0 >= p.stat_split;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int n = n0 + (wn * TN + tn) * 32 + ln;
         const bool n_ok = n < s.Cout;
-        const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+        const float bv = (ACT && p.bias && n_ok) ? p.bias[n] : 0.f;
         float ssum = 0.f, ssq = 0.f, ssum1 = 0.f, ssq1 = 0.f;      // second pair: rows >= p.stat_split
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                int m = mb + (i & 3) + 8 * (i >> 2);
-                float v = acc[tm][tn][i];
+                const int m = mb + (i & 3) + 8 * (i >> 2);
+                const float v = acc[tm][tn][i];
                 if (m < M && n_ok) {
-                    const bool second = m >= p.stat_split;
-                    ssum += second ? 0.f : v;
-                    ssq += second ? 0.f : v * v;
-                    ssum1 += second ? v : 0.f;
-                    ssq1 += second ? v * v : 0.f;
-                    size_t pix = (size_t)m;
-                    if (MODE == IN_DGRAD && rowtab) pix = (size_t)rowtab[m - m0];
+                    if (STATS == 1) {
+                        ssum += v;
+                        ssq += v * v;
+                    } else if (STATS == 2) {
+                        const bool second = m >= p.stat_split;
+                        ssum += second ? 0.f : v;
+                        ssq += second ? 0.f : v * v;
+                        ssum1 += second ? v : 0.f;
+                        ssq1 += second ? v * v : 0.f;
+                    }
                     if (MODE == IN_DGRAD && p.split_c1 > 0) {
                         // gradient of cat([upsample2x(a), skip]): a gets the 2x2 sum, skip its own channels
                         if (n < p.split_c1) {
@@ -104,22 +112,31 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
                                 atomicAdd(p.y + cp * p.split_c1 + n, v + pair);
                             }
                         } else {
+                            const size_t pix = rowtab ? (size_t)rowtab[m - m0] : (size_t)m;
                             p.y2[pix * (s.Cout - p.split_c1) + (n - p.split_c1)] = v;
                         }
                     } else {
-                        p.y[pix * s.Cout + n] = apply_act(v + bv, p.act);
+                        const size_t pix = (MODE == IN_DGRAD && rowtab) ? (size_t)rowtab[m - m0] : (size_t)m;
+                        p.y[pix * s.Cout + n] = ACT ? apply_act(v + bv, p.act) : v;
                     }
                 }
             }
         }
-        if (p.stats) {
-            ssum += __shfl_xor(ssum, 32, 64);
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (lh == 0 && n_ok) {
-                atomicAdd(p.stats + n, ssum);
-                atomicAdd(p.stats + s.Cout + n, ssq);
+        if (STATS) {
+            if (STATS == 1 && tile_second) {
+                ssum1 = ssum;
+                ssq1 = ssq;
+                ssum = ssq = 0.f;
             }
-            if (p.stat_split != 0x7fffffff) {
+            if (STATS == 2 || !tile_second) {
+                ssum += __shfl_xor(ssum, 32, 64);
+                ssq += __shfl_xor(ssq, 32, 64);
+                if (lh == 0 && n_ok) {
+                    atomicAdd(p.stats + n, ssum);
+                    atomicAdd(p.stats + s.Cout + n, ssq);
+                }
+            }
+            if (STATS == 2 || tile_second) {
                 ssum1 += __shfl_xor(ssum1, 32, 64);
                 ssq1 += __shfl_xor(ssq1, 32, 64);
                 if (lh == 0 && n_ok) {
@@ -128,6 +145,31 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
                 }
             }
         }
+    }
+}
+
+template <int TM, int TN, int MODE>
+__device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int lane, int M, int Hr, int Wr, int rstep, int oy0, int ox0,
+                                              const int* rowtab, int bm) {
+    (void)Hr; (void)Wr; (void)rstep; (void)oy0; (void)ox0;
+    const bool act = p.bias != nullptr || p.act != ACT_NONE;          // workgroup-uniform dispatch
+    int stats = 0;
+    if (MODE != IN_DGRAD && p.stats) {
+        const int bm_rows = TM * 32 * (wm + 1);                        // rows of the tile at or below this wave
+        (void)bm_rows;
+        stats = (m0 < p.stat_split && m0 + bm > p.stat_split) ? 2 : 1;
+    }
+    if (MODE == IN_DGRAD) {
+        conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+    } else if (stats == 0) {
+        if (act) conv_epilogue_body<TM, TN, MODE, 0, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        else conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+    } else if (stats == 1) {
+        if (act) conv_epilogue_body<TM, TN, MODE, 1, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        else conv_epilogue_body<TM, TN, MODE, 1, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+    } else {
+        conv_epilogue_body<TM, TN, MODE, 2, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
     }
 }
 
