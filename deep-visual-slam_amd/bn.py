@@ -79,6 +79,8 @@ class _BNAct(torch.autograd.Function):
         g_par, b_par, rg_par, rb_par = ctx.affine
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
+        for par in ctx.affine:
+            gradsink.note(par, torch.cuda.current_stream())
         ds_res = residual is not None and res_fin is not None
         d_res = None
         if residual is not None:

@@ -210,11 +210,17 @@ class _Conv2d(torch.autograd.Function):
             # fully sunk (nothing goes back to autograd): run beside the data-gradient chain on the side stream
             side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
             if side is None:
+                if wsink is not None or bsink is not None:
+                    gradsink.note(weight, torch.cuda.current_stream())
+                    gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
                 dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
                                       in_scale=scale, in_shift=shift, nchw_planar=planar,
                                       pooled=weight.grad is not None, dw_out=wsink, db_out=bsink)
             else:
-                side.wait_stream(torch.cuda.current_stream())
+                cur = torch.cuda.current_stream()
+                gradsink.note(weight, cur, side)
+                gradsink.note(ctx.bias_ref, cur, side)
+                side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
                                  in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink)
@@ -253,6 +259,8 @@ class _HeadConv(torch.autograd.Function):
         wsink, bsink = gradsink.target(ctx.params[0]), gradsink.target(ctx.params[1])
         if wsink is not None and not wsink.permute(0, 2, 3, 1).is_contiguous():
             wsink = None
+        gradsink.note(ctx.params[0], torch.cuda.current_stream())
+        gradsink.note(ctx.params[1], torch.cuda.current_stream())
         dw = wsink if wsink is not None else zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
         db = bsink if bsink is not None else (zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None)
         check(_lib.lib().dvs_conv2d_head_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(),

@@ -104,6 +104,9 @@ class GradSync:
         self._ready = [0] * len(self.buckets)
         self._reduced = [False] * len(self.buckets)
         self._work = []
+        self._members = [[] for _ in self.buckets]       # parameters of each bucket (for the stream fence)
+        for i, p in enumerate(flat.tensors):
+            self._members[self.bucket_of[i]].append(p)
         if self.world > 1:
             # fires once per backward, after the last use of the parameter -- also for sunk gradients, whose
             # Functions hand None to autograd (gradsink.py)
@@ -116,7 +119,9 @@ class GradSync:
             if self._ready[b] == self.sizes[b] and not self._reduced[b]:
                 s, e = self.buckets[b]
                 self._reduced[b] = True
-                gradsink.fence()         # the bucket's gradients were written on several streams
+                # the bucket's gradients were written on the compute and side streams of ITS network only: wait for
+                # those, not for the other network's backward
+                gradsink.fence_for(self._members[b])
                 self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
         return hook

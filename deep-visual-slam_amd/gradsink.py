@@ -16,10 +16,20 @@ has returned, also when every one of them returned None (tests/test_dp_cpu.py pi
 
 
 class Sink:
-    __slots__ = ("grad",)
+    __slots__ = ("grad", "streams")
 
     def __init__(self, grad):
         self.grad = grad
+        self.streams = ()          # streams whose kernels accumulated into `grad` in the current backward (see note)
+
+
+def note(param, *streams):
+    """Backward: remember which streams wrote this parameter's sunk gradient, so that a data-parallel bucket only
+    has to wait for the streams of its own parameters (fence_for) -- PoseNet's buckets must not wait for DepthNet's
+    backward and vice versa."""
+    s = getattr(param, "_dvs_sink", None) if param is not None else None
+    if s is not None:
+        s.streams = tuple(st for st in streams if st is not None)
 
 
 def attach(param, grad_view):
@@ -79,6 +89,27 @@ def join():
         for (dev, _), (_, side) in _side.items():
             if dev == cur.device_index:
                 cur.wait_stream(side)
+
+
+def fence_for(params):
+    """The current stream waits for the streams noted on `params` (all of them: fence(), when a parameter has no note,
+    i.e. its gradient came through autograd on the current stream or from code that does not note)."""
+    notes = [getattr(getattr(p, "_dvs_sink", None), "streams", ()) or () for p in params]
+    if not any(notes):
+        if _side:
+            fence()                # GPU run, nothing noted: be safe
+        return                     # CPU tensors
+    if not all(notes):
+        fence()                    # a gradient of this bucket came through autograd (e.g. the stems): wait for everything
+        return
+    cur = torch.cuda.current_stream()
+    seen = {cur.cuda_stream}
+    for p in params:
+        s = getattr(p, "_dvs_sink", None)
+        for st in (s.streams if s is not None else ()):
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                cur.wait_stream(st)
 
 
 def fence():
