@@ -48,10 +48,11 @@ def build_gpu(batch, num_scales, device, rank):
     depth_net = DepthNet(18, pretrained=False).to(device).train()
     pose_net = PoseNet(18, pretrained=False, num_input_images=2).to(device).train()
     flat = dp.FlatParams(dp.trainable_parameters(depth_net, pose_net))
-    sync = dp.GradSync(flat)
-    opt = dp.FusedAdam(flat, lr=1e-4)
     trainer = MonodepthTrainer(depth_net, pose_net, train_config(batch, num_scales), device)
     trainer.num_scales = num_scales
+    hook_streams = ({id(p): trainer.pose_stream for p in pose_net.parameters()} if trainer.pose_stream is not None else None)
+    sync = dp.GradSync(flat, hook_streams=hook_streams)
+    opt = dp.FusedAdam(flat, lr=1e-4)
     sample = synth.throughput_sample(batch, H, W, rank=rank, device=device)
     return trainer, flat, sync, opt, sample
 
@@ -151,11 +152,19 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # rehearsal of the N > 1 code path on a one-GPU box: DVS_BENCH_REHEARSE=1 puts every rank on cuda:0 and carries the
+    # all-reduce over gloo (the numbers mean nothing then; the driver's multi-GPU runs use RCCL, one GPU per rank)
+    rehearse = os.environ.get("DVS_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     import __graft_entry__ as entry
     if rank == 0:

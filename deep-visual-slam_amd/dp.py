@@ -84,7 +84,11 @@ class FlatParams:
 class GradSync:
     """Bucketed sum all-reduce of FlatParams.grads, overlapped with backward."""
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None):
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, hook_streams=None):
+        """hook_streams: optional {id(param): torch.cuda.Stream}.  Autograd creates a parameter's AccumulateGrad node
+        -- and binds it to the then-current stream -- when the hook is registered; parameters whose backward runs on
+        another stream (PoseNet's, see MonodepthTrainer.pose_stream) should be registered under that stream, otherwise
+        every accumulation first synchronises the two streams."""
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -111,7 +115,12 @@ class GradSync:
             # fires once per backward, after the last use of the parameter -- also for sunk gradients, whose
             # Functions hand None to autograd (gradsink.py)
             for i, p in enumerate(flat.tensors):
-                p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
+                st = hook_streams.get(id(p)) if hook_streams else None
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
+                else:
+                    p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
 
     def _make_hook(self, b):
         def hook(_param):
