@@ -24,6 +24,19 @@
 
 __device__ __attribute__((aligned(16))) float g_dvs_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
+// Buffer-addressed LDS-DMA: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The per-lane byte offset (row, tap) is
+// loop-invariant, the per-stage part (channel block / weight column) is a scalar, and a lane that must contribute zeros
+// (padding, rows past the end) carries an offset beyond the descriptor's num_records: the hardware range check returns 0.
+// No address arithmetic, no zero-page select: a DMA row costs NO vector-ALU instruction in the K loop.
+constexpr int OOB_OFF = 0x7ffffff0;          // + any in-range scalar offset stays < 2^32 and >= num_records (< 2^31)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes,
+                                             soff_bytes, 0, 0);
+}
+
 __device__ __forceinline__ void dma16(const float* gp, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -96,7 +109,6 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
         bid_z = 0;
     }
     const int m0 = bid_x * BM, n0 = bid_y * BN;
-    const float* const zero_page = p.zero_page;
 
     int Hr = s.Ho, Wr = s.Wo, rstep = 1, oy0 = 0, ox0 = 0, ky0 = 0, kx0 = 0;
     if (MODE == IN_DGRAD && s.stride == 2) {         // parity classes, see conv_fwd_kernel
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     const int ntap = s.kh * s.kw, nC = s.Cin / BK;   // taps of this launch / class, 32-channel blocks per tap
 
     // ---- prologue: per (DMA row, tap) element offsets (NO_TAP: padding, row past the end) ----------------------
-    constexpr int NO_TAP = -2147483647 - 1;          // the concat source's offsets are rebased by -C1 and may be negative
+    constexpr int NO_TAP = OOB_OFF;                   // byte offset beyond every tensor: the buffer load returns zeros
     const int rsub = lane >> 3, slot = lane & 7;
     int toff[A_INS][MAXTAP];                         // into p.x   (IN_UPCAT: the half-resolution source)
     int toff2[(MODE == IN_UPCAT) ? A_INS : 1][MAXTAP];   // into p.t.x2 (IN_UPCAT only)
@@ -159,44 +171,41 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
                 int off = 0, off2 = 0;
                 if (MODE == IN_DGRAD) dgrad_tap_setup(p.s, r_b[j], r_y[j], r_x[j], ky0 + rstep * tky, kx0 + rstep * tkx, ok, off);
                 else tap_setup<MODE>(s, p.t, r_b[j], r_y[j] + tky, r_x[j] + tkx, ok, off, off2);
-                toff[j][t] = ok ? off + r_q[j] : NO_TAP;
-                if (MODE == IN_UPCAT) toff2[j][t] = ok ? off2 + r_q[j] : NO_TAP;
+                toff[j][t] = ok ? (off + r_q[j]) * 4 : NO_TAP;                              // bytes
+                if (MODE == IN_UPCAT) toff2[j][t] = ok ? (off2 + p.t.C1 + r_q[j]) * 4 : NO_TAP;   // undo tap_setup's -C1 rebasing
             }
         }
     }
-    const float* b_ptr[B_INS];
+    int b_off[B_INS];                                // byte offset of my weight row + k-chunk (rows past Cout: out of range)
 #pragma unroll
     for (int j = 0; j < B_INS; ++j) {
         const int row = (wave * B_INS + j) * 8 + rsub;
         const int n = n0 + row;
-        // rows past Cout read the zero page every stage: their pointer is the page itself, advanced by 0 (see issue)
-        b_ptr[j] = (n < s.Cout) ? p.w + (size_t)n * p.s.Ktot + ((slot ^ ((row >> 1) & 7)) << 2) : nullptr;
+        b_off[j] = (n < s.Cout) ? (n * p.s.Ktot + ((slot ^ ((row >> 1) & 7)) << 2)) * 4 : NO_TAP;
     }
+    // buffer descriptors (sizes in bytes; the host only selects this kernel for tensors < 2 GiB)
+    const size_t x_elems = (MODE == IN_UPCAT) ? (size_t)s.B * (s.H >> 1) * (s.W >> 1) * p.t.C1 : (size_t)s.B * s.H * s.W * s.Cin;
+    const __amdgpu_buffer_rsrc_t rx = dma_rsrc(p.x, x_elems * 4);
+    const __amdgpu_buffer_rsrc_t rx2 = (MODE == IN_UPCAT && p.t.x2 != p.x)
+                                           ? dma_rsrc(p.t.x2, (size_t)s.B * s.H * s.W * (s.Cin - p.t.C1) * 4) : rx;
+    const __amdgpu_buffer_rsrc_t rw = dma_rsrc(p.w, (size_t)p.s.Cout * p.s.Ktot * 4);
 
     // stage (tap T, channel block c) -> LDS buffer `buf`.  T is a compile-time constant: toff[.][T] is a register.
     auto issue = [&](auto tc, int c, int buf) {
         constexpr int T = decltype(tc)::value;
         const int ci0 = c * BK;
-        const float* src = p.x;
-        int cadd = ci0;
-        bool use2 = false;
-        if (MODE == IN_UPCAT) {
-            use2 = ci0 >= p.t.C1;                                    // workgroup-uniform
-            src = use2 ? p.t.x2 : p.x;
-        }
+        if (MODE == IN_UPCAT && ci0 >= p.t.C1) {                     // workgroup-uniform: the skip source
+            const int soff = (ci0 - p.t.C1) * 4;
 #pragma unroll
-        for (int j = 0; j < A_INS; ++j) {
-            int off = toff[j][T];
-            if (MODE == IN_UPCAT) off = use2 ? toff2[j][T] : off;   // toff2 already carries the -C1 channel rebasing
-            const float* gp = off != NO_TAP ? src + (off + cadd) : zero_page;
-            dma16(gp, As + (buf * BM + (wave * A_INS + j) * 8) * BK);
-        }
-        const int kc = kc_tap[T] + ci0;
+            for (int j = 0; j < A_INS; ++j) dma16_buf(rx2, toff2[j][T], soff, As + (buf * BM + (wave * A_INS + j) * 8) * BK);
+        } else {
+            const int soff = ci0 * 4;
 #pragma unroll
-        for (int j = 0; j < B_INS; ++j) {
-            const float* gp = b_ptr[j] ? b_ptr[j] + kc : zero_page;
-            dma16(gp, Bs + (buf * BN + (wave * B_INS + j) * 8) * BK);
+            for (int j = 0; j < A_INS; ++j) dma16_buf(rx, toff[j][T], soff, As + (buf * BM + (wave * A_INS + j) * 8) * BK);
         }
+        const int kc = (kc_tap[T] + ci0) * 4;
+#pragma unroll
+        for (int j = 0; j < B_INS; ++j) dma16_buf(rw, b_off[j], kc, Bs + (buf * BN + (wave * B_INS + j) * 8) * BK);
     };
 
     f32x16 acc[TM][TN];

@@ -384,6 +384,9 @@ template <int MODE, bool FOLD>
 bool dma_eligible(const FwdParams& p) {
     static const bool enabled = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
     if (!enabled || FOLD || MODE == IN_PLANAR || (p.s.Cin % BK) != 0 || p.s.kh > 3 || p.s.kw > 3) return false;
+    // buffer-descriptor addressing with an out-of-range sentinel: every operand below 2 GiB
+    const double lim = 2147483648.0 / 4;
+    if ((double)p.s.B * p.s.H * p.s.W * p.s.Cin >= lim || (double)p.s.Cout * p.s.Ktot >= lim) return false;
     if (MODE == IN_DGRAD) return p.t.dact == 0 && p.s.pad_mode == PAD_ZERO && p.split_c1 == 0;
     return true;
 }
