@@ -340,6 +340,19 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
     }
 }
 
+// Buffer-addressed LDS-DMA: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The per-lane byte offset (row, tap) is
+// loop-invariant, the per-stage part (channel block / weight column) is a scalar, and a lane that must contribute zeros
+// (padding, rows past the end) carries an offset beyond the descriptor's num_records: the hardware range check returns 0.
+// No address arithmetic, no zero-page select: a DMA row costs NO vector-ALU instruction in the K loop.
+constexpr int OOB_OFF = 0x7ffffff0;          // + any in-range scalar offset stays < 2^32 and >= num_records (< 2^31)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes,
+                                             soff_bytes, 0, 0);
+}
+
 // conv_stem.hip: kernels specialised for the ResNet stems (7x7, stride 2, planar 3- / 6-channel image -> 64 channels)
 bool stem_shape(const ConvShape& s);
 void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, const float* sc, const float* sh,

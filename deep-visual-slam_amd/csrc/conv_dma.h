@@ -24,19 +24,6 @@
 
 __device__ __attribute__((aligned(16))) float g_dvs_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
-// Buffer-addressed LDS-DMA: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The per-lane byte offset (row, tap) is
-// loop-invariant, the per-stage part (channel block / weight column) is a scalar, and a lane that must contribute zeros
-// (padding, rows past the end) carries an offset beyond the descriptor's num_records: the hardware range check returns 0.
-// No address arithmetic, no zero-page select: a DMA row costs NO vector-ALU instruction in the K loop.
-constexpr int OOB_OFF = 0x7ffffff0;          // + any in-range scalar offset stays < 2^32 and >= num_records (< 2^31)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const float* base, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t r, int voff_bytes, int soff_bytes, float* lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes,
-                                             soff_bytes, 0, 0);
-}
-
 __device__ __forceinline__ void dma16(const float* gp, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

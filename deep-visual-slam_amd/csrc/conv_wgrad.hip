@@ -333,61 +333,59 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     const int co0 = bid_x * BM, k0 = bid_y * BN;
     const int m_begin = bid_z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
 
-    // one pixel of the ring per thread: (b, oy, ox) -> window origin (y0, x0) and its element offset
+    // one pixel of the ring per thread: (b, oy, ox) -> byte offset of the window origin and a 9-bit mask of the taps that
+    // fall inside the image (the 2-D bounds test, done once per pixel instead of once per lane and stage)
     auto fill_ring = [&](int half, int m_first) {
         const int m = m_first + tid;
         int2 e;
         e.x = 0;
-        e.y = (int)0x80008000u;                              // y0 = x0 = -32768: never inside the image
+        e.y = 0;                                             // no tap valid
         if (m < m_end) {
             const int b = m / (s.Ho * s.Wo), rem = m - b * (s.Ho * s.Wo);
             const int oy = rem / s.Wo, ox = rem - oy * s.Wo;
             const int y0 = oy * s.stride - s.pad, x0 = ox * s.stride - s.pad;
-            e.x = ((b * s.H + y0) * s.W + x0) * s.Cin;
-            e.y = (int)(((unsigned)y0 << 16) | ((unsigned)x0 & 0xffffu));
+            e.x = ((b * s.H + y0) * s.W + x0) * s.Cin * 4;
+            int mask = 0;
+            for (int t = 0; t < s.kh * s.kw; ++t) {
+                const int tky = t / s.kw, tkx = t - tky * s.kw;
+                if ((unsigned)(y0 + tky) < (unsigned)s.H && (unsigned)(x0 + tkx) < (unsigned)s.W) mask |= 1 << t;
+            }
+            e.y = mask;
         }
         ptab[half][tid] = e;
     };
 
-    // dY rows: pointer of my 16-byte slice in the first stage, advanced by BP rows per stage
+    // Buffer-addressed LDS-DMA (see conv_dma.h): per-lane byte offsets are loop-invariant, the stage's pixel block is a
+    // scalar offset, lanes that must read zeros carry an out-of-range offset.  The dY descriptor ends at this split's
+    // last pixel, so the tail rows of the last stage are zero-filled by the range check.
+    constexpr int OOB = OOB_OFF;
+    const auto rdy = dma_rsrc(p.dy, (size_t)m_end * s.Cout * 4);
+    const auto rxs = dma_rsrc(p.x, (size_t)s.B * s.H * s.W * s.Cin * 4);
     const int d_c = (lane % DV) * 4, d_r = lane / DV;
-    const bool co_ok = co0 + d_c < s.Cout;
-    const float* d_ptr[D_INS];
-    int d_m[D_INS];
+    int d_off[D_INS];
 #pragma unroll
-    for (int j = 0; j < D_INS; ++j) {
-        d_m[j] = m_begin + (wave * D_INS + j) * D_RPI + d_r;
-        d_ptr[j] = p.dy + (size_t)d_m[j] * s.Cout + min(co0 + d_c, s.Cout - 4);
-    }
+    for (int j = 0; j < D_INS; ++j)
+        d_off[j] = (co0 + d_c < s.Cout) ? (((wave * D_INS + j) * D_RPI + d_r) * s.Cout + co0 + d_c) * 4 : OOB;
     // X rows: my tap and channel slice are fixed; the pixel comes from the ring
     const int x_c = (lane % XV) * 4, x_r = lane / XV;
     const int k = k0 + x_c;
     const bool k_ok = k < s.Ktot;
     const int kc = min(k, s.Ktot - 4), tap = kc / s.Cin, ci = kc - tap * s.Cin, ky = tap / s.kw, kx = tap - ky * s.kw;
-    const int lane_off = (ky * s.W + kx) * s.Cin + ci;
-    const size_t d_step = (size_t)BP * s.Cout;
+    const int lane_off = ((ky * s.W + kx) * s.Cin + ci) * 4;
+    const int tap_bit = k_ok ? (1 << tap) : 0;
 
     auto issue_stage = [&](int mb, int buf) {
         const int ring = (mb - m_begin) & (2 * PT - 1);               // position of the stage's first pixel in the ring
+        const int d_soff = mb * s.Cout * 4;                           // scalar: first pixel row of the stage
 #pragma unroll
-        for (int j = 0; j < D_INS; ++j) {
-            const float* gp = (d_m[j] < m_end && co_ok) ? d_ptr[j] : g_dvs_zero_page_w;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)&Ds[buf][(wave * D_INS + j) * D_RPI][0],
-                                             16, 0, 0);
-            d_m[j] += BP;
-            d_ptr[j] += d_step;
-        }
+        for (int j = 0; j < D_INS; ++j)
+            dma16_buf(rdy, d_off[j], d_soff, &Ds[buf][(wave * D_INS + j) * D_RPI][0]);
 #pragma unroll
         for (int j = 0; j < X_INS; ++j) {
             const int slot = ring + (wave * X_INS + j) * X_RPI + x_r;
             const int2 e = (&ptab[0][0])[slot];
-            const int y = (e.y >> 16) + ky, x = (int)(short)(e.y & 0xffff) + kx;
-            const bool ok = k_ok && (unsigned)y < (unsigned)s.H && (unsigned)x < (unsigned)s.W;
-            const float* gp = ok ? p.x + (e.x + lane_off) : g_dvs_zero_page_w;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                             (__attribute__((address_space(3))) void*)&Xs[buf][(wave * X_INS + j) * X_RPI][0],
-                                             16, 0, 0);
+            const int voff = (e.y & tap_bit) ? e.x + lane_off : OOB;
+            dma16_buf(rxs, voff, 0, &Xs[buf][(wave * X_INS + j) * X_RPI][0]);
         }
     };
 
@@ -466,8 +464,8 @@ void launch_cfg(WgradParams p, hipStream_t st) {
         static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
         static const int dbg = dvs::experiment_flags("DVS_CONV_DEBUG_NOBARRIER");
         p.dbg = dbg & 4;
-        if (dma && MODE == IN_NHWC && p.s.pad_mode == PAD_ZERO && p.t.dact == 0 && p.dbias == nullptr && p.s.H < 32768 &&
-            p.s.W < 32768) {
+        if (dma && MODE == IN_NHWC && p.s.pad_mode == PAD_ZERO && p.t.dact == 0 && p.dbias == nullptr && p.s.kh * p.s.kw <= 30 &&
+            (double)p.s.B * p.s.H * p.s.W * p.s.Cin < 536870912.0 && (double)M * p.s.Cout < 536870912.0) {
             hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
             return;
         }
