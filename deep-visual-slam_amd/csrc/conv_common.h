@@ -360,4 +360,9 @@ void stem_wgrad(const float* x, const float* dy, float* dw, const ConvShape& s, 
 void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_groups, const ConvShape& s,
               const float* sc, const float* sh, hipStream_t st);
 
+// conv_thin.hip: weight gradient of the decoder's thin full-resolution layers (Cout 16 / 32, reflection-padded 3x3);
+// returns false (nothing launched) when the shape is not one of them
+bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
+                hipStream_t st);
+
 }  // namespace dvsconv

@@ -516,6 +516,8 @@ int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, c
         dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
         stem_wgrad(x, dy, dw, s, p.t.in_scale, p.t.in_shift, st);
+    } else if (!planar && thin_wgrad(x, dy, dw, dbias, s, p.t, st)) {
+        // decoder layers with 16 / 32 output channels: conv_thin.hip
     } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st);
         else launch_mode<IN_PLANAR, false>(p, st);

@@ -32,6 +32,10 @@ CASES = [
     ("relu_bias_1x1", 2, 512, 256, 1, 1, 0, False, 7, 9, "relu", True),
     ("relu_bias_3x3", 2, 256, 256, 3, 1, 1, False, 7, 9, "relu", True),
     ("odd_tail", 1, 20, 36, 3, 1, 1, False, 11, 17, None, True),
+    # decoder layers with 16 / 32 output channels at segment-aligned widths: the row-ring weight-gradient kernel
+    ("thin32_c64", 2, 64, 32, 3, 1, 1, True, 13, 64, "elu", True),
+    ("thin16_c32", 2, 32, 16, 3, 1, 1, True, 21, 128, "elu", True),
+    ("thin16_c16_nobias", 1, 16, 16, 3, 1, 1, True, 9, 256, None, False),
 ]
 
 
@@ -56,7 +60,7 @@ def test_conv_fwd_bwd(gpu_device, case):
         assert relmax(a, r) < 1e-4, (nm, relmax(a, r))
 
 
-@pytest.mark.parametrize("c1,c2,co,H,W", [(32, 64, 32, 24, 40), (256, 256, 128, 10, 14)])
+@pytest.mark.parametrize("c1,c2,co,H,W", [(32, 64, 32, 24, 40), (256, 256, 128, 10, 14), (32, 64, 32, 26, 96)])
 def test_upsample_concat_conv(gpu_device, c1, c2, co, H, W):
     """upsample(x) ; cat([x, skip]) ; ConvBlock (model/depthnet.py:79-88) as one call."""
     from deep_visual_slam_amd import conv as DC
@@ -74,6 +78,26 @@ def test_upsample_concat_conv(gpu_device, c1, c2, co, H, W):
     assert relmax(y, y_ref) < 2e-5
     g = torch.autograd.grad(y, [xa, xb, w, b], cot)
     for a, r, nm in zip(g, g_ref, ("dxa", "dxb", "dw", "db")):
+        assert a.shape == r.shape and relmax(a, r) < 1e-4, (nm, relmax(a, r))
+
+
+@pytest.mark.parametrize("c,co,H,W", [(16, 16, 20, 128), (32, 32, 10, 24)])
+def test_upsample_only_conv(gpu_device, c, co, H, W):
+    """upsample(x) ; ConvBlock with nothing concatenated (decoder level 0, model/depthnet.py:79-88)."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(2)
+    B = 2
+    xa = torch.randn(B, c, H // 2, W // 2, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, c, 3, 3, device=gpu_device) * 0.08).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(co, device=gpu_device) * 0.1).requires_grad_(True)
+    up = F.interpolate(xa, scale_factor=2, mode="nearest")
+    y_ref = F.elu(F.conv2d(F.pad(up, (1,) * 4, mode="reflect"), w, b))
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [xa, w, b], cot)
+    y = DC.conv2d(xa, w, b, 1, 0, 1, "elu", upsample=True)
+    assert relmax(y, y_ref) < 2e-5
+    g = torch.autograd.grad(y, [xa, w, b], cot)
+    for a, r, nm in zip(g, g_ref, ("dxa", "dw", "db")):
         assert a.shape == r.shape and relmax(a, r) < 1e-4, (nm, relmax(a, r))
 
 
