@@ -364,5 +364,7 @@ void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_g
 // returns false (nothing launched) when the shape is not one of them
 bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
                 hipStream_t st);
+bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const ConvShape& s, const InXform& t, int act,
+              hipStream_t st);
 
 }  // namespace dvsconv

@@ -471,6 +471,18 @@ void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
     const int M = s.B * s.Ho * s.Wo;
     // DVS_CONV_TILE=small: 64-row tiles everywhere (more, lighter workgroups; tuning experiments)
     static const bool small = [] { const char* e = getenv("DVS_CONV_TILE"); return e && e[0] == 's'; }();
+    if constexpr (MODE == IN_DGRAD && !FOLD) {
+        // upconv_1_1's data gradient (N = 96 input channels): three 32-column tiles per wave instead of a 128-wide tile
+        // that is one quarter padding
+        static const bool n96 = [] { const char* e = getenv("DVS_CONV_N96"); return !(e && e[0] == '0'); }();
+        if (n96 && s.Cout == 96 && !dma_eligible<MODE, FOLD>(p)) {
+            FwdParams q = p;
+            q.dbg_nobarrier = 0;
+            if (conv_nbuf() == 2) launch_buf<128, 96, 4, 1, MODE, FOLD, 2>(q, st, slot);
+            else launch_buf<128, 96, 4, 1, MODE, FOLD, 1>(q, st, slot);
+            return;
+        }
+    }
     if (s.Cout > 64) {
         // few output pixels (layer3/4, pose decoder): halve the M tile so the grid still covers the 256 CUs
         if (small || ((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
@@ -591,6 +603,8 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
         dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
         stem_fwd(x, w, y, p.stats, f && f->stat_groups == 2 ? 2 : 1, s, p.t.in_scale, p.t.in_shift, st);
+    } else if (!planar && !p.stats && thin_fwd(x, w, bias, y, s, p.t, p.act, st)) {
+        // 16-output-channel decoder layers: conv_thin.hip
     } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st, dvs::SLOT_CONV_FWD);
         else launch_mode<IN_PLANAR, false>(p, st, dvs::SLOT_CONV_FWD);

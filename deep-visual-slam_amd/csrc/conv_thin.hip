@@ -240,6 +240,143 @@ void launch_thin(ThinParams p, hipStream_t st) {
     hipLaunchKernelGGL((thin_wgrad_kernel<MT, CIN, SEG>), dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward of the 16-output-channel layers (upconv_0_0: 32 -> 16 at 240x320, upconv_0_1: upsample(16) -> 16 at 480x640).
+// N = 16 fills half of the generic kernel's narrowest (32-column) tile and a 16- / 32-channel K stage cannot use the
+// LDS-DMA path, so those two layers ran at 32 / 41 TF.  Same row ring as the weight gradient above, roles swapped:
+// A = pixels x (tap, channel) read from the ring (16 pixel lanes at stride CIN + 2 floats: conflict-free), B = the
+// layer's whole weight matrix held in registers (9 CIN / 4 values per lane), v_mfma_f32_16x16x4_f32, bias +
+// activation on the accumulators, direct NHWC store.
+struct ThinFwdParams {
+    const float* x;      // [B,H,W,CIN], or [B,H/2,W/2,CIN] when up
+    const float* w;      // [16][9][CIN]
+    const float* bias;   // [16] or NULL
+    float* y;            // [B,H,W,16]
+    int B, H, W, up, act;
+    int nseg, rows_per_wg, row_chunks;
+};
+
+__device__ __forceinline__ float thin_act(float v, int act) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.f);
+        case ACT_ELU: return v > 0.f ? v : __expf(v) - 1.f;     // absolute error ~1e-7 (one v_exp_f32 instead of expm1f's polynomial)
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+template <int CIN, int SEG>
+__global__ __launch_bounds__(NT) void thin_fwd_kernel(ThinFwdParams p) {
+    constexpr int CO = 16;
+    constexpr int CS = CIN + 2;                          // pixel stride: 16 pixel lanes x 2 channel groups = 32 distinct banks
+    constexpr int COLS = SEG + 2, ROWF = COLS * CS;
+    constexpr int XV = CIN / 4, ROW_VECS = COLS * XV, X_LOADS = (ROW_VECS + NT - 1) / NT;
+    constexpr int PXW = SEG / 4, PT = PXW / 16;          // pixels / 16-pixel tiles of a stage per wave
+    constexpr int C4 = CIN / 4, KSTEPS = 9 * C4;
+    static_assert(PXW % 16 == 0 && (ROWF % 2) == 0, "shape");
+    __shared__ __attribute__((aligned(16))) float Ps[4 * ROWF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lg = xcd_logical(blockIdx.x, gridDim.x, 1);
+    const int chunk = lg % p.row_chunks;
+    lg /= p.row_chunks;
+    const int seg = lg % p.nseg, b = lg / p.nseg;
+    const int oy_begin = chunk * p.rows_per_wg, oy_end = min(p.H, oy_begin + p.rows_per_wg);
+    const int x0 = seg * SEG;
+    const int H1 = p.up ? p.H >> 1 : p.H, W1 = p.up ? p.W >> 1 : p.W;
+
+    int x_goff[X_LOADS], x_loff[X_LOADS];
+    bool x_ok[X_LOADS];
+#pragma unroll
+    for (int j = 0; j < X_LOADS; ++j) {
+        const int idx = tid + NT * j;
+        x_ok[j] = idx < ROW_VECS;
+        const int px = min(idx, ROW_VECS - 1) / XV, c = (min(idx, ROW_VECS - 1) % XV) * 4;
+        const int sx = reflect_i(x0 - 1 + px, p.W);
+        x_goff[j] = (p.up ? sx >> 1 : sx) * CIN + c;
+        x_loff[j] = px * CS + c;
+    }
+    f32x4 rx[X_LOADS];
+    auto load_row = [&](int pr) {
+        const int sr = reflect_i(pr - 1, p.H);
+        const float* r1 = p.x + ((size_t)b * H1 + (p.up ? sr >> 1 : sr)) * W1 * CIN;
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j) rx[j] = *reinterpret_cast<const f32x4*>(r1 + x_goff[j]);
+    };
+    auto store_row = [&](int pr) {
+        float* dst = Ps + (pr & 3) * ROWF;
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j)
+            if (x_ok[j]) {                               // CS is even, not a multiple of 4: two 8-byte stores
+                float2* d2 = reinterpret_cast<float2*>(dst + x_loff[j]);
+                d2[0] = float2{rx[j][0], rx[j][1]};
+                d2[1] = float2{rx[j][2], rx[j][3]};
+            }
+    };
+
+    // B operand: lane (n = lane & 15, kidx = lane >> 4) holds W[n][tap][4 c4 + kidx] for every k-step (tap, c4)
+    const int n = lane & 15, kidx = lane >> 4;
+    float wreg[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) wreg[s] = p.w[(size_t)n * (9 * CIN) + (s / C4) * CIN + (s % C4) * 4 + kidx];
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    const int a_lane = (wave * PXW + n) * CS + kidx;     // pixel lane & 15 of my first tile, channel kidx
+
+    if (oy_begin < oy_end) {
+        for (int pr = oy_begin; pr < oy_begin + 3; ++pr) {
+            load_row(pr);
+            store_row(pr);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int oy = oy_begin; oy < oy_end; ++oy) {
+        const bool more = oy + 1 < oy_end;
+        if (more) load_row(oy + 3);
+        const float* Ar[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) Ar[ky] = Ps + ((oy + ky) & 3) * ROWF + a_lane;
+        f32x4 acc[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int tap = s / C4, c4 = s % C4, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) acc[t] = mma(Ar[ky][(t * 16 + kx) * CS + c4 * 4], wreg[s], acc[t]);
+        }
+        // C/D map: pixel = 4 (lane >> 4) + r, channel = lane & 15
+        float* yrow = p.y + (((size_t)b * p.H + oy) * p.W + x0 + wave * PXW + 4 * kidx) * CO + n;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yrow[(t * 16 + r) * CO] = thin_act(acc[t][r] + bv, p.act);
+        if (more) store_row(oy + 3);
+        __syncthreads();
+    }
+}
+
+template <int CIN, int SEG>
+void launch_thin_fwd(ThinFwdParams p, hipStream_t st) {
+    p.nseg = p.W / SEG;
+    static const int slots = [] {
+        int occ = 0, dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, thin_fwd_kernel<CIN, SEG>, NT, 0) != hipSuccess || occ < 1) occ = 1;
+        return cus * occ;
+    }();
+    const int cols = p.B * p.nseg;
+    int chunks = max(1, min(slots / cols, p.H / 8));
+    p.rows_per_wg = (p.H + chunks - 1) / chunks;
+    p.row_chunks = (p.H + p.rows_per_wg - 1) / p.rows_per_wg;
+    dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
+    prof.work(2.0 * p.B * p.H * p.W * 16 * 9.0 * CIN);
+    hipLaunchKernelGGL((thin_fwd_kernel<CIN, SEG>), dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
+}
+
 }  // namespace
 
 bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
@@ -259,6 +396,24 @@ bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const 
     else if (s.Cout == 32 && s.Cin == 64 && s.W % 32 == 0) launch_thin<32, 64, 32>(p, st);
     else if (s.Cout == 16 && s.Cin == 32 && s.W % 64 == 0) launch_thin<16, 32, 64>(p, st);
     else if (s.Cout == 16 && s.Cin == 16 && s.W % 128 == 0) launch_thin<16, 16, 128>(p, st);
+    else return false;
+    return true;
+}
+
+}  // namespace dvsconv
+
+namespace dvsconv {
+
+bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const ConvShape& s, const InXform& t, int act,
+              hipStream_t st) {
+    static const bool enabled = [] { const char* e = getenv("DVS_CONV_THIN"); return !(e && e[0] == '0'); }();
+    if (!enabled || s.kh != 3 || s.kw != 3 || s.stride != 1 || s.pad != 1 || s.pad_mode != PAD_REFLECT || t.in_scale) return false;
+    if (s.Cout != 16 || s.H < 8 || (t.x2 && (t.C1 != s.Cin || ((s.H | s.W) & 1)))) return false;     // upsample-only or plain
+    ThinFwdParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.B = s.B; p.H = s.H; p.W = s.W; p.up = t.x2 != nullptr; p.act = act;
+    if (s.Cin == 16 && s.W % 128 == 0) launch_thin_fwd<16, 128>(p, st);
+    else if (s.Cin == 32 && s.W % 64 == 0) launch_thin_fwd<32, 64>(p, st);
     else return false;
     return true;
 }
