@@ -366,5 +366,7 @@ bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const 
                 hipStream_t st);
 bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const ConvShape& s, const InXform& t, int act,
               hipStream_t st);
+bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out, int dact, int B, int H, int W, int Cin,
+                int Cout, int split_c1, float* dx_skip, hipStream_t st);
 
 }  // namespace dvsconv

@@ -553,6 +553,9 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     p.y2 = dx_skip;
     p.split_c1 = C1;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->pad_mode == PAD_REFLECT && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+        thin_dgrad(dy, wt, dx, y_out, dact, d->B, d->H, d->W, d->Cin, d->Cout, C1, dx_skip, st))
+        return dvs::check_launch("dvs_conv2d_dgrad");      // 16-output-channel decoder layers: conv_thin.hip
     launch_mode<IN_DGRAD, false>(p, st, dvs::SLOT_CONV_DGRAD);
     return dvs::check_launch("dvs_conv2d_dgrad");
 }

@@ -377,6 +377,216 @@ void launch_thin_fwd(ThinFwdParams p, hipStream_t st) {
     hipLaunchKernelGGL((thin_fwd_kernel<CIN, SEG>), dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of the same two layers (dY has 16 channels; dX has 32 channels at 240x320 / 16 channels summed 2x2 into
+// the 240x320 tensor that was upsampled).  The generic kernel multiplied dY by ELU'(Y) nine times per element, padded N
+// to 32 and, for upconv_0_1, reduced the 2x2 blocks with 29 M global atomics (22 TF).  Row ring again:
+//   dX[y][x] = sum_{ky,kx} W[.][ky][kx][.]^T dZ[y + 1 - ky][x + 1 - kx]     (dZ = dY * act'(Y), zero outside the image)
+//   + the reflection fold: what the mirrored border of the padded input received comes back to row 1 / H-2 and column
+//     1 / W-2.  Those are EXTRA k-steps, not epilogue work: row 1 also multiplies dZ row 0 by the ky = 0 taps (row H-2:
+//     dZ row H-1, ky = 2) -- the whole stage, a uniform branch; column 1 also multiplies dZ column 0 by the kx = 0 taps
+//     (column W-2: column W-1, kx = 2) -- one lane of one edge tile, every other lane of that tile reads the ring's zero
+//     halo entry instead.
+//   * dZ rows are staged once per workgroup (activation derivative applied there), weights live in registers;
+//   * the 2x2 sum of the upsample gradient is two rows accumulated into the same accumulators plus an in-lane add of
+//     register pairs (the 16x16 C/D map keeps 4 consecutive pixels in a lane): plain stores, no atomics.
+struct ThinDgradParams {
+    const float* dy;     // [B,H,W,16]
+    const float* y;      // forward output or NULL
+    const float* wt;     // packed [Cin][9][16] (dvs_conv2d_pack_wt)
+    float* dx;           // [B,H,W,NOUT], or [B,H/2,W/2,16] when UP
+    int B, H, W, dact;
+    int nseg, rows_per_wg, row_chunks;
+};
+
+template <int NOUT, int SEG, bool UP>
+__global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
+    constexpr int CK = 16, CS = CK + 2, C4 = CK / 4;
+    constexpr int COLS = SEG + 2, ROWF = COLS * CS;
+    constexpr int ROW_VECS = COLS * C4, X_LOADS = (ROW_VECS + NT - 1) / NT;
+    constexpr int PXW = SEG / 4, PT = PXW / 16, NTN = NOUT / 16;
+    static_assert(PXW % 16 == 0 && (!UP || NOUT == 16), "shape");
+    __shared__ __attribute__((aligned(16))) float Ps[4 * ROWF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lg = xcd_logical(blockIdx.x, gridDim.x, 1);
+    const int chunk = lg % p.row_chunks;
+    lg /= p.row_chunks;
+    const int seg = lg % p.nseg, b = lg / p.nseg;
+    const int iy_begin = chunk * p.rows_per_wg, iy_end = min(p.H, iy_begin + p.rows_per_wg);
+    const int x0 = seg * SEG;
+
+    // ---- dZ row staging: entry e of a ring row is image column x0 - 1 + e; columns / rows outside the image are zeros
+    int x_goff[X_LOADS], x_loff[X_LOADS];
+    bool x_ok[X_LOADS], x_in[X_LOADS];
+#pragma unroll
+    for (int j = 0; j < X_LOADS; ++j) {
+        const int idx = tid + NT * j;
+        x_ok[j] = idx < ROW_VECS;
+        const int e = min(idx, ROW_VECS - 1) / C4, c = (min(idx, ROW_VECS - 1) % C4) * 4;
+        const int col = x0 - 1 + e;
+        x_in[j] = (unsigned)col < (unsigned)p.W;
+        x_goff[j] = clampi(col, p.W) * CK + c;
+        x_loff[j] = e * CS + c;
+    }
+    f32x4 rd[X_LOADS], ry[X_LOADS];
+    bool row_in = false;
+    auto load_row = [&](int d) {                          // dZ row d (may be -1 or H: zeros)
+        row_in = (unsigned)d < (unsigned)p.H;
+        const size_t ro = ((size_t)b * p.H + clampi(d, p.H)) * p.W * CK;
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j) {
+            rd[j] = *reinterpret_cast<const f32x4*>(p.dy + ro + x_goff[j]);
+            if (p.dact) ry[j] = *reinterpret_cast<const f32x4*>(p.y + ro + x_goff[j]);
+        }
+    };
+    auto store_row = [&](int d) {
+        float* dst = Ps + ((d + 1) & 3) * ROWF;
+#pragma unroll
+        for (int j = 0; j < X_LOADS; ++j)
+            if (x_ok[j]) {
+                f32x4 v = rd[j];
+                const bool in = row_in && x_in[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = p.dact ? v[e] * act_grad_from_out(ry[j][e], p.dact) : v[e];
+                    v[e] = in ? g : 0.f;
+                }
+                float2* d2 = reinterpret_cast<float2*>(dst + x_loff[j]);
+                d2[0] = float2{v[0], v[1]};
+                d2[1] = float2{v[2], v[3]};
+            }
+    };
+
+    // ---- B operand: lane (n = lane & 15 [+ 16 nt], kidx) holds W[co = 4 c4 + kidx][tap][ci = n] = wt[(ci * 9 + tap) * 16 + co]
+    const int n = lane & 15, kidx = lane >> 4;
+    float wreg[NTN][9 * C4];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+        for (int s = 0; s < 9 * C4; ++s)
+            wreg[nt][s] = p.wt[((size_t)(nt * 16 + n) * 9 + s / C4) * CK + (s % C4) * 4 + kidx];
+    const int a_lane = (wave * PXW + n) * CS + kidx;       // + (16 t + 2 - kx) CS: entry of pixel (lane & 15) of tile t, tap kx
+    // column fold: the one lane whose pixel is image column 1 (first segment, wave 0, tile 0) / W - 2 (last segment, last
+    // wave, last tile) reads entry 1 (column 0) / SEG (column W - 1); the other lanes of that tile read the zero halo entry
+    const bool edge_l = seg == 0 && wave == 0, edge_r = seg == p.nseg - 1 && wave == 3;
+    const int fold_l = ((n == 1) ? 1 : 0) * CS + kidx;
+    const int fold_r = ((n == 14) ? SEG : SEG + 1) * CS + kidx;
+
+    f32x4 acc[PT][NTN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    if (iy_begin < iy_end) {
+        for (int d = iy_begin - 1; d <= iy_begin + 1; ++d) {
+            load_row(d);
+            store_row(d);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int iy = iy_begin; iy < iy_end; ++iy) {
+        const bool more = iy + 1 < iy_end;
+        if (more) load_row(iy + 2);
+        auto taps = [&](const float* row, int ky) {       // the three kx taps of weight row ky on one dZ row of the ring
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        const float a = row[a_lane + (t * 16 + 2 - kx) * CS + c4 * 4];
+#pragma unroll
+                        for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = mma(a, wreg[nt][(ky * 3 + kx) * C4 + c4], acc[t][nt]);
+                    }
+                }
+        };
+        auto col_fold = [&](const float* row, int ky) {   // edge tiles only: kx = 0 on column 0 / kx = 2 on column W - 1
+            if (edge_l) {
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) {
+                    const float a = row[fold_l + c4 * 4];
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt) acc[0][nt] = mma(a, wreg[nt][(ky * 3 + 0) * C4 + c4], acc[0][nt]);
+                }
+            }
+            if (edge_r) {
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) {
+                    const float a = row[fold_r + c4 * 4];
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt) acc[PT - 1][nt] = mma(a, wreg[nt][(ky * 3 + 2) * C4 + c4], acc[PT - 1][nt]);
+                }
+            }
+        };
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = Ps + ((iy + 2 - ky) & 3) * ROWF;      // dZ row iy + 1 - ky lives in slot (d + 1) & 3
+            taps(row, ky);
+            col_fold(row, ky);
+        }
+        if (iy == 1) {                                    // + what padded row 0 received: dZ row 0 through the ky = 0 taps
+            const float* row = Ps + 1 * ROWF;
+            taps(row, 0);
+            col_fold(row, 0);
+        }
+        if (iy == p.H - 2) {                              // + padded row H + 1: dZ row H - 1 through the ky = 2 taps
+            const float* row = Ps + (p.H & 3) * ROWF;
+            taps(row, 2);
+            col_fold(row, 2);
+        }
+        // C/D map: pixel = 4 (lane >> 4) + r, channel = lane & 15
+        if (UP) {
+            if (iy & 1) {                                 // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
+                float* orow = p.dx + (((size_t)b * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + ((x0 + wave * PXW + 4 * kidx) >> 1)) * 16 + n;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    orow[(t * 8 + 0) * 16] = acc[t][0][0] + acc[t][0][1];
+                    orow[(t * 8 + 1) * 16] = acc[t][0][2] + acc[t][0][3];
+                }
+                zero_acc();
+            }
+        } else {
+            float* orow = p.dx + (((size_t)b * p.H + iy) * p.W + x0 + wave * PXW + 4 * kidx) * NOUT + n;
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) orow[(t * 16 + r) * NOUT + nt * 16] = acc[t][nt][r];
+            zero_acc();
+        }
+        if (more) store_row(iy + 2);
+        __syncthreads();
+    }
+}
+
+template <int NOUT, int SEG, bool UP>
+void launch_thin_dgrad(ThinDgradParams p, hipStream_t st) {
+    p.nseg = p.W / SEG;
+    static const int slots = [] {
+        int occ = 0, dev = 0, cus = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, thin_dgrad_kernel<NOUT, SEG, UP>, NT, 0) != hipSuccess || occ < 1) occ = 1;
+        return cus * occ;
+    }();
+    const int cols = p.B * p.nseg;
+    int chunks = max(1, min(slots / cols, p.H / 8));
+    p.rows_per_wg = ((p.H + chunks - 1) / chunks + 1) & ~1;   // even: a 2x2 block never straddles two workgroups
+    p.row_chunks = (p.H + p.rows_per_wg - 1) / p.rows_per_wg;
+    dvs::ProfScope prof(dvs::SLOT_CONV_DGRAD, st);
+    prof.work(2.0 * p.B * p.H * p.W * 16 * 9.0 * NOUT);
+    hipLaunchKernelGGL((thin_dgrad_kernel<NOUT, SEG, UP>), dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
+}
+
 }  // namespace
 
 bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
@@ -414,6 +624,23 @@ bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const
     p.B = s.B; p.H = s.H; p.W = s.W; p.up = t.x2 != nullptr; p.act = act;
     if (s.Cin == 16 && s.W % 128 == 0) launch_thin_fwd<16, 128>(p, st);
     else if (s.Cin == 32 && s.W % 64 == 0) launch_thin_fwd<32, 64>(p, st);
+    else return false;
+    return true;
+}
+
+}  // namespace dvsconv
+
+namespace dvsconv {
+
+// arguments as dvs_conv2d_dgrad receives them: H, W, Cin = the forward conv's (logical, full-resolution) input, Cout = 16
+bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out, int dact, int B, int H, int W, int Cin,
+                int Cout, int split_c1, float* dx_skip, hipStream_t st) {
+    static const bool enabled = [] { const char* e = getenv("DVS_CONV_THIN"); return !(e && e[0] == '0'); }();
+    if (!enabled || Cout != 16 || H < 8 || dx_skip) return false;
+    ThinDgradParams p{};
+    p.dy = dy; p.y = y_out; p.wt = wt; p.dx = dx; p.B = B; p.H = H; p.W = W; p.dact = dact;
+    if (split_c1 == 16 && Cin == 16 && W % 128 == 0 && !((H | W) & 1)) launch_thin_dgrad<16, 128, true>(p, st);
+    else if (split_c1 == 0 && Cin == 32 && W % 64 == 0) launch_thin_dgrad<32, 64, false>(p, st);
     else return false;
     return true;
 }
