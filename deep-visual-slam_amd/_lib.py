@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
 MAX_SCALES = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp = C.c_void_p
 
@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
 
 class ConvFusion(C.Structure):
     _fields_ = [("x2", _vp), ("C1", C.c_int), ("in_scale", _vp), ("in_shift", _vp), ("in_relu", C.c_int),
-                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp), ("stat_groups", C.c_int)]
+                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp), ("stat_groups", C.c_int), ("residual", _vp)]
 
 
 _SIGNATURES = {

@@ -62,8 +62,10 @@ def _geometry(x, w_shape, x2, nchw_planar):
     return x, x2, B, Cin, H, W
 
 
-def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None, stat_groups=1):
+def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None, stat_groups=1, residual=None):
     f = ConvFusion()
+    if residual is not None:
+        f.residual = residual.data_ptr()      # NHWC memory, checked by the caller
     if x2 is UPSAMPLE_ONLY:
         f.x2, f.C1 = x.data_ptr(), x.shape[1]      # C1 == Cin: the second source is never read
     elif x2 is not None:
@@ -84,9 +86,10 @@ def _pack_planar_weight(weight):
 
 
 def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=None, x2=None, in_scale=None,
-                   in_shift=None, in_relu=False, nchw_planar=False, stats=None, stat_groups=1):
+                   in_shift=None, in_relu=False, nchw_planar=False, stats=None, stat_groups=1, residual=None):
     """Raw forward launch (no autograd).  x: logical [B,Cin,H,W] (NHWC memory, or planar NCHW when
-    nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1)."""
+    nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1); residual (inference only): a tensor of
+    the output's shape added before the activation."""
     if not (x.is_cuda and weight.is_cuda):
         raise _lib.DvsError("conv2d: GPU tensors only; this package has no CPU path")
     x, x2, B, Cin, H, W = _geometry(x, tuple(weight.shape), x2, nchw_planar)
@@ -94,7 +97,11 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
     d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
     Ho, Wo = out_hw(H, W, d.kh, d.kw, stride, pad)
     y = torch.empty((B, d.Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
-    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats, stat_groups)
+    if residual is not None:
+        residual = _nhwc(residual)
+        if tuple(residual.shape) != tuple(y.shape):
+            raise _lib.DvsError("conv2d_forward: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats, stat_groups, residual)
     check(_lib.lib().dvs_conv2d_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), C.byref(f),
                                     _lib.stream()), "dvs_conv2d_fwd")
     return y

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     // N tile fastest, then M tile: the tiles that share an im2col slice are neighbours on one XCD (xcd_logical).
     // The four parity classes of a stride-2 data gradient carry 1, 2, 2 and 4 taps: dealt round-robin in launch order
     // (M tile fastest, class slowest, no remap) they balance across the XCDs; contiguous ranges measured 1.6x slower.
-    int bid_x, bid_y, bid_z;
+    int bid_x, bid_y, bid_z, ks = 0;
     if (p.g.z > 1) {
         int lg = blockIdx.x;
         bid_x = lg % p.g.x;
@@ -90,7 +90,14 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
         bid_y = lg % p.g.y;
         bid_z = lg / p.g.y;
     } else {
-        int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y, p.g.remap);
+        // split-K launches (p.ksplit > 1, small-M inference layers): the K slices of one tile are launch neighbours
+        const int tiles = p.g.x * p.g.y;
+        int lg = blockIdx.x;
+        if (p.ksplit > 1) {
+            ks = lg % p.ksplit;
+            lg /= p.ksplit;
+        }
+        lg = xcd_logical(lg, tiles, p.ksplit > 1 ? 0 : p.g.remap);
         bid_y = lg % p.g.y;
         bid_x = lg / p.g.y;
         bid_z = 0;
@@ -114,6 +121,9 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
     const int M = s.B * Hr * Wr;
     if (m0 >= M) return;
     const int ntap = s.kh * s.kw, nC = s.Cin / BK;   // taps of this launch / class, 32-channel blocks per tap
+    // my K slice: channel blocks [c_lo, c_hi) of every tap (the whole range unless this is a split-K launch)
+    const int c_per = (nC + p.ksplit - 1) / max(p.ksplit, 1);
+    const int c_lo = p.ksplit > 1 ? ks * c_per : 0, c_hi = p.ksplit > 1 ? min(nC, c_lo + c_per) : nC;
 
     // ---- prologue: per (DMA row, tap) element offsets (NO_TAP: padding, row past the end) ----------------------
     constexpr int NO_TAP = OOB_OFF;                   // byte offset beyond every tensor: the buffer load returns zeros
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
         buf ^= 1;
     };
     if (ntap > 0) {
-        issue(std::integral_constant<int, 0>{}, 0, 0);
+        issue(std::integral_constant<int, 0>{}, c_lo, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -219,12 +229,12 @@ __global__ __launch_bounds__(NT) void conv_dma_kernel(FwdParams p) {
         constexpr int T = decltype(tc)::value;
         if (T < ntap) {                                         // workgroup-uniform
 #pragma unroll 1
-            for (int c = 0; c + 1 < nC; ++c) {
+            for (int c = c_lo; c + 1 < c_hi; ++c) {
                 issue(tc, c + 1, buf ^ 1);                      // lands in the other buffer while this one is multiplied
                 compute_and_sync();
             }
             if constexpr (T + 1 < MAXTAP) {
-                if (T + 1 < ntap) issue(std::integral_constant<int, T + 1>{}, 0, buf ^ 1);
+                if (T + 1 < ntap) issue(std::integral_constant<int, T + 1>{}, c_lo, buf ^ 1);
             }
             compute_and_sync();
         }

@@ -31,6 +31,9 @@ struct FwdParams {
     int split_c1;        // ... channels < split_c1 are summed 2x2 into the coarse tensor y ([B,H/2,W/2,C1]) with atomics
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
     const float* zero_page;   // 16 bytes of zeros: what the LDS-DMA kernel fetches for padding / tail lanes
+    const float* res;         // [B,Ho,Wo,Cout] added before the activation (inference BasicBlock tail), or NULL
+    int ksplit;               // > 1: split-K launch of the LDS-DMA kernel -- raw partial sums are added into a zero-filled y
+                              // with atomics, splitk_finish_kernel applies bias / residual / activation afterwards
     Grid3 g;             // logical grid: M tiles, N tiles, parity classes (launched 1-D, see xcd_logical)
     ConvShape s;
     InXform t;
@@ -71,7 +74,7 @@ __device__ __forceinline__ void fill_row_table(const FwdParams& p, const ConvSha
 // dispatch and 64-bit index arithmetic it does not need are paid in matrix throughput):
 //   STATS 0: none   1: whole tile in one statistics group   2: tile straddles the group boundary (per-element test)
 //   ACT   false: plain store (no bias, no activation)       true: + bias, runtime activation
-template <int TM, int TN, int MODE, int STATS, bool ACT>
+template <int TM, int TN, int MODE, int STATS, bool ACT, bool RES = false>
 __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const ConvShape& s, f32x16 (&acc)[TM][TN], int m0,
                                                    int n0, int wm, int wn, int lane, int M, const int* rowtab, int bm) {
     // C/D map of the 32x32 MFMA: n = lane & 31, m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -117,7 +120,8 @@ __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const Con
                         }
                     } else {
                         const size_t pix = (MODE == IN_DGRAD && rowtab) ? (size_t)rowtab[m - m0] : (size_t)m;
-                        p.y[pix * s.Cout + n] = ACT ? apply_act(v + bv, p.act) : v;
+                        const float rv = RES ? p.res[pix * s.Cout + n] : 0.f;
+                        p.y[pix * s.Cout + n] = ACT ? apply_act(v + bv + rv, p.act) : v;
                     }
                 }
             }
@@ -162,8 +166,24 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
     }
     if (MODE == IN_DGRAD) {
         conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+    } else if (p.ksplit > 1) {
+        const int ln = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + (wn * TN + tn) * 32 + ln;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = mb + (i & 3) + 8 * (i >> 2);
+                    if (m < M && n < s.Cout) atomicAdd(p.y + (size_t)m * s.Cout + n, acc[tm][tn][i]);
+                }
+            }
+        }
     } else if (stats == 0) {
-        if (act) conv_epilogue_body<TM, TN, MODE, 0, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        if (p.res) conv_epilogue_body<TM, TN, MODE, 0, true, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        else if (act) conv_epilogue_body<TM, TN, MODE, 0, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
         else conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
     } else if (stats == 1) {
         if (act) conv_epilogue_body<TM, TN, MODE, 1, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
@@ -396,6 +416,19 @@ inline int xcd_remap_enabled() {
     return on;
 }
 
+// y = act(y + bias + residual) over [M][Cout], 4 channels per thread: second half of a split-K forward
+__global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, size_t nvec, int cout4, int act) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    f32x4 v = reinterpret_cast<f32x4*>(y)[i];
+    if (bias) v += reinterpret_cast<const f32x4*>(bias)[i % cout4];
+    if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+    reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
@@ -416,12 +449,34 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     prof.work(2.0 * M * p.s.Cout * (double)p.s.Ktot * eff);
     FwdParams q = p;
     q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
+    q.ksplit = 1;
+    if constexpr (MODE != IN_DGRAD) {
+        // Few output pixels (batch-1 inference: 300 ... 4800 rows in layers 2-4 and the coarse decoder levels) leave most
+        // of the 256 CUs without a tile while each tile walks a K of thousands: split the channel blocks over several
+        // workgroups.  Training batches never get here (their grids cover the chip and they need the statistics epilogue).
+        static const bool splitk = [] { const char* e = getenv("DVS_CONV_SPLITK"); return !(e && e[0] == '0'); }();
+        const int tiles = grid.x * grid.y, nC = p.s.Cin / BK;
+        if (splitk && !p.stats && tiles < 128 && nC >= 2 && (p.s.Cout & 3) == 0) {
+            int want = min(nC, (256 + tiles - 1) / tiles);
+            const int per = (nC + want - 1) / want;
+            q.ksplit = (nC + per - 1) / per;
+        }
+    }
     static const float* zp = [] {
         void* d = nullptr;
         (void)hipGetSymbolAddress(&d, HIP_SYMBOL(g_dvs_zero_page));
         return static_cast<const float*>(d);
     }();
     q.zero_page = zp;
+    if (q.ksplit > 1) {
+        const size_t nvec = (size_t)M * p.s.Cout / 4;
+        (void)hipMemsetAsync(p.y, 0, nvec * 16, st);
+        hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * q.ksplit), dim3(NT), lds, st, q);
+        if (p.bias || p.res || p.act != ACT_NONE)
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, p.y, p.bias, p.res,
+                               nvec, p.s.Cout / 4, p.act);
+        return;
+    }
     hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(NT), lds, st, q);
 }
 
@@ -582,7 +637,8 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     if (f) {
         p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
         p.t.in_relu = f->in_relu; planar = f->nchw_planar;
-        p.act = f->act; p.stats = f->stats;
+        p.act = f->act; p.stats = f->stats; p.res = f->residual;
+        DVS_REQUIRE(!(f->residual && f->stats), "dvs_conv2d_fwd: residual and stats are exclusive (inference vs training)");
         DVS_REQUIRE(f->stat_groups >= 0 && f->stat_groups <= 2 && (f->stat_groups != 2 || (d->B % 2) == 0),
                     "dvs_conv2d_fwd: stat_groups is 0, 1 or 2 (2 needs an even batch)");
         p.stat_split = (f->stat_groups == 2) ? (d->B / 2) * s.Ho * s.Wo : 0x7fffffff;
@@ -602,11 +658,11 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
-    if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE) {
+    if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE && !p.res) {
         dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
         stem_fwd(x, w, y, p.stats, f && f->stat_groups == 2 ? 2 : 1, s, p.t.in_scale, p.t.in_shift, st);
-    } else if (!planar && !p.stats && thin_fwd(x, w, bias, y, s, p.t, p.act, st)) {
+    } else if (!planar && !p.stats && !p.res && thin_fwd(x, w, bias, y, s, p.t, p.act, st)) {
         // 16-output-channel decoder layers: conv_thin.hip
     } else if (planar) {
         if (fold) launch_mode<IN_PLANAR, true>(p, st, dvs::SLOT_CONV_FWD);

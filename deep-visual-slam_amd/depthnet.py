@@ -36,8 +36,16 @@ class DepthNet(nn.Module):
             self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
+        # inference only (eval() + no_grad): compute just these disparity heads, e.g. (0,) for vo/predict.py:79-80 which
+        # reads ("disp", 0) alone; None = every scale, as the reference does
+        self.inference_scales = None
         # weights live as [Cout][kh][kw][Cin] in memory (same logical shapes / state_dict)
         self.to(memory_format=torch.channels_last)
+
+    def _wanted(self, scale):
+        if self.training or torch.is_grad_enabled() or self.inference_scales is None:
+            return True
+        return scale in self.inference_scales
 
     def forward(self, input_data) -> dict:
         input_features = self.encoder(input_data)
@@ -48,6 +56,6 @@ class DepthNet(nn.Module):
             # upsample(x) ; cat skip ; ConvBlock -- one fused gather + conv (model/depthnet.py:80-85)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, upsample=True)
-            if i in self.scales:
+            if i in self.scales and self._wanted(i):
                 self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")
         return self.outputs

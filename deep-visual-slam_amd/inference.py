@@ -1,0 +1,60 @@
+"""Inference path of the networks (callers vo/predict.py:20-42,63-86, vo/eval_traj.py,
+vo/eval_redwood.py:325-350 and the ROS2 node): `.eval()` + `torch.no_grad()`, batch 1, `("disp", 0)` and the 6-DoF pose.
+
+Nothing has to change in those callers: in that mode `nn_ops.conv_bn_act` folds every BatchNorm into the convolution in
+front of it and lets the conv epilogue add the identity and apply the ReLU (one kernel per conv, `dvs_conv_fusion.residual`).
+This module adds the two optional extras a real-time loop wants:
+
+  * `depth_net.inference_scales = (0,)`   skip the three coarse disparity heads nobody reads at inference;
+  * `Graphed(net, example)`               capture `net(example)` into a HIP graph and replay it per frame -- at batch 1
+                                          the ~90 launches of a frame are issue-bound from Python (unlike the training
+                                          step, where eager issue is faster than a graph).
+"""
+import torch
+
+from . import _lib
+
+
+class Graphed:
+    """net(x) for one fixed input shape, replayed from a captured HIP graph.
+
+    The returned tensors are the graph's static outputs: consume (or clone) them before the next call.  The network's
+    weights are read at replay time, but the BatchNorm fold is part of the capture: call `refresh()` after loading new
+    weights."""
+
+    def __init__(self, net, example, warmup=3):
+        if net.training:
+            raise _lib.DvsError("Graphed: put the network in eval() mode first (training steps are issued eagerly)")
+        if not example.is_cuda:
+            raise _lib.DvsError("Graphed: GPU tensors only; this package has no CPU path")
+        self.net = net
+        self.static_in = example.detach().clone()
+        self.warmup = warmup
+        self.refresh()
+
+    def refresh(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():        # warm-up off the capture: lazy initialisation, fold cache
+            for _ in range(self.warmup):
+                self.net(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = self.net(self.static_in)
+
+    def __call__(self, x):
+        if x.shape != self.static_in.shape:
+            raise _lib.DvsError("Graphed: captured for input %s, got %s" % (tuple(self.static_in.shape), tuple(x.shape)))
+        self.static_in.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
+def prepare(depth_net, pose_net, scales=(0,)):
+    """eval() both networks and restrict DepthNet to the disparity heads an inference caller reads."""
+    depth_net.eval()
+    pose_net.eval()
+    depth_net.inference_scales = tuple(scales) if scales is not None else None
+    return depth_net, pose_net

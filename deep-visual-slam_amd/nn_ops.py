@@ -76,6 +76,35 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     return _ACT[act](F.conv2d(x, weight, bias, stride, padding))
 
 
+_fold_cache = {}
+
+
+def folded_bn(weight, bn):
+    """(w', b') with an eval-mode BatchNorm2d folded into the convolution in front of it:
+    bn(conv(x, w)) = conv(x, w * s) + (beta - running_mean * s),  s = gamma / sqrt(running_var + eps).
+    Cached per weight tensor and refreshed when any of the five tensors is modified in place (optimiser step,
+    load_state_dict), so an inference loop pays for the fold once."""
+    gamma = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
+    beta = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_var)
+    key = id(weight)
+    ver = (weight._version, gamma._version, beta._version, bn.running_mean._version, bn.running_var._version,
+           weight.data_ptr(), bn.running_mean.data_ptr(), bn.eps)
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        s = gamma / torch.sqrt(bn.running_var + bn.eps)
+        w_f = (weight * s.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
+        b_f = (beta - bn.running_mean * s).contiguous()
+    _fold_cache[key] = (ver, w_f, b_f)
+    return w_f, b_f
+
+
+def inference_mode(bn):
+    """The fast path below applies when nothing will be differentiated and the BatchNorm uses its running statistics."""
+    return (not bn.training) and bn.track_running_stats and bn.running_mean is not None and not torch.is_grad_enabled()
+
+
 def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None):
     """relu(bn(conv(x)) + residual') -- the conv -> BatchNorm2d -> (+identity) -> ReLU groups of torchvision's
     BasicBlock / stem (model/resnet_encoder.py:100-111).  `residual` is the identity tensor; `res` =
@@ -84,6 +113,17 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
     _require_gpu(x, "conv_bn_act")
     from . import bn as _bn
     planar = planar_norm is not None
+    if (inference_mode(bn) and conv_backend() == "hip" and _conv.supported(x, weight, None, planar)
+            and (res is None or (inference_mode(res[1]) and _conv.supported(residual, res[0])))):
+        # inference (vo/predict.py:20-42,63-86: .eval() + torch.no_grad()): BatchNorm folded into the weights, bias +
+        # identity + ReLU in the conv epilogue -- one kernel per conv, no normalisation passes
+        sc, sh = planar_norm if planar else (None, None)
+        if res is not None:
+            wd, bd = folded_bn(res[0], res[1])
+            residual = _conv.conv2d_forward(residual, wd, bd, res[2], 0)
+        w_f, b_f = folded_bn(weight, bn)
+        return _conv.conv2d_forward(x, w_f, b_f, stride, padding, act="relu" if relu else None, in_scale=sc, in_shift=sh,
+                                    nchw_planar=planar, residual=residual)
     fused = (conv_backend() == "hip" and _conv.supported(x, weight, None, planar) and _bn.supported_c(weight.shape[0], bn)
              and (res is None or (_conv.supported(residual, res[0]) and _bn.supported_c(res[0].shape[0], res[1]))))
     G = _batch_groups

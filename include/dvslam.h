@@ -102,6 +102,9 @@ typedef struct {
     int stat_groups;        /* 0 / 1: one set of statistics; 2: stats is [2][2][Cout], the first and second half of
                                the batch counted separately -- PoseNet runs its two frame pairs as one batch of 2B
                                and the reference's two calls (vo/learner_new.py:113-114) normalise each pair alone */
+    const float* residual;  /* non-NULL: [B,Ho,Wo,Cout] added before the activation: y = act(conv + bias + residual) --
+                               the BasicBlock tail relu(bn2(conv2(.)) + identity) with an eval-mode BatchNorm folded
+                               into w / bias (inference path of model/resnet_encoder.py:100-111) */
 } dvs_conv_fusion;
 
 /* y [B,Ho,Wo,Cout] = act(conv(x, w) + bias); `f` may be NULL (no fusion). */

@@ -18,8 +18,12 @@ def family(n):
         targs = base.split("<")[1].split(",") if "<" in base else []
         mode = targs[4].strip() if len(targs) > 4 else "?"
         return "conv_dgrad_kernel" if mode.startswith("3") or "IN_DGRAD" in mode else "conv_fwd_kernel"
-    if "conv_wgrad" in n or "stem_wgrad" in n:
+    if "conv_wgrad" in n or "stem_wgrad" in n or "thin_wgrad" in n:
         return "conv_wgrad_kernel"
+    if "thin_fwd" in n:
+        return "conv_fwd_kernel"
+    if "thin_dgrad" in n:
+        return "conv_dgrad_kernel"
     if "bn_bwd" in n:
         return "bn_bwd_kernel"
     if "bn_apply_fwd" in n or "bn_finalize" in n:
