@@ -125,6 +125,70 @@ def cpu_baseline(batch, num_scales, steps=2, warmup=1):
                       % (steps, warmup, batch, num_scales, dt)}
 
 
+def inference_side(device, with_cpu):
+    """BASELINE.json configs[0] on the GPU: depth-only forward of one 640x480 frame (eval() + no_grad, the inference
+    path of deep_visual_slam_amd/inference.py), and the whole per-frame work of vo/predict.py:63-86 (PoseNet on the
+    frame pair + pose matrix + DepthNet + depth), eager and as a HIP-graph replay; the CPU oracle's eval-mode DepthNet
+    on the same frame beside it."""
+    from deep_visual_slam_amd import inference
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    from deep_visual_slam_amd.layers import transformation_from_parameters, disp_to_depth
+    torch.manual_seed(0)
+    dn, pn = DepthNet(18, pretrained=False).to(device), PoseNet(18, pretrained=False, num_input_images=2).to(device)
+    inference.prepare(dn, pn, scales=(0,))
+    g = torch.Generator().manual_seed(1234)
+    tgt, pair = torch.rand(1, 3, H, W, generator=g).to(device), torch.rand(1, 6, H, W, generator=g).to(device)
+
+    def depth_only(depth, pose):
+        return depth(tgt)[("disp", 0)]
+
+    def frame(depth, pose):
+        aa, t = pose(pair)
+        T = transformation_from_parameters(aa[:, 0], t[:, 0], invert=False)
+        _, d = disp_to_depth(depth(tgt)[("disp", 0)], 0.1, 10.0)
+        return T, d
+
+    def timeit(fn, depth, pose, n=100):
+        with torch.no_grad():
+            for _ in range(10):
+                fn(depth, pose)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn(depth, pose)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    res = {"workload": "configs[0]: depth-only forward, one 640x480 frame, ResNet-18 encoder + DepthDecoder (eval, batch 1)",
+           "unit": "frames/s"}
+    t = timeit(depth_only, dn, pn)
+    res["value"] = 1.0 / t
+    res["ms_per_frame"] = t * 1e3
+    t = timeit(frame, dn, pn)
+    gd, gp = inference.Graphed(dn, tgt), inference.Graphed(pn, pair)
+    tg = timeit(frame, gd, gp)
+    res["predict_frame"] = {"workload": "PoseNet(pair) + pose matrix + DepthNet(frame) + depth, as vo/predict.py:63-86",
+                            "eager_frames_per_s": 1.0 / t, "graph_frames_per_s": 1.0 / tg,
+                            "eager_ms": t * 1e3, "graph_ms": tg * 1e3}
+    if with_cpu:
+        from oracle import networks as ON
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in dn.state_dict().items()}
+        x = tgt.cpu()
+        with torch.no_grad():
+            ON.depthnet(x, sd, train=False)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ON.depthnet(x, sd, train=False)
+            tc = (time.perf_counter() - t0) / 3
+        res["cpu_baseline"] = {"value": 1.0 / tc, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "3 timed + 1 warm-up eval-mode DepthNet forwards of the same frame, oracle/networks.py "
+                                         "on PyTorch-CPU fp32, %.3f s/frame" % tc}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +350,9 @@ def main():
             out["other_configs"] = {"configs[1]": {"workload": c2["name"], "value": 3.0 * c2["batch"] * args.steps / dt2,
                                                    "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
                                                    "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"]}}
+            del tr2, sync2, opt2, sample2
+            torch.cuda.empty_cache()
+            out["other_configs"]["configs[0]"] = inference_side(device, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
