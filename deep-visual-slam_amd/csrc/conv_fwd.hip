@@ -429,6 +429,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(float* __restrict__ 
     reinterpret_cast<f32x4*>(y)[i] = v;
 }
 
+// Zero fill of a split-K output.  A kernel, not hipMemsetAsync: inside a captured HIP graph the memset node was not
+// reliably ordered before the kernel node that accumulates into the buffer (replays of a graph captured after another
+// one lost partial sums, tools/dbg_graph.py); kernel -> kernel edges are.
+__global__ __launch_bounds__(256) void splitk_zero_kernel(float* __restrict__ y, size_t nvec) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nvec) reinterpret_cast<f32x4*>(y)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
@@ -470,7 +478,7 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     q.zero_page = zp;
     if (q.ksplit > 1) {
         const size_t nvec = (size_t)M * p.s.Cout / 4;
-        (void)hipMemsetAsync(p.y, 0, nvec * 16, st);
+        hipLaunchKernelGGL(splitk_zero_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, p.y, nvec);
         hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * q.ksplit), dim3(NT), lds, st, q);
         if (p.bias || p.res || p.act != ACT_NONE)
             hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, p.y, p.bias, p.res,

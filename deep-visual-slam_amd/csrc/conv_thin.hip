@@ -41,6 +41,14 @@ struct Acc {
     using type = typename std::conditional<MT == 32, f32x16, f32x4>::type;
 };
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_thin(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_thin<I + 1, N>(f);
+    }
+}
+
 __device__ __forceinline__ f32x16 mma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -126,7 +134,10 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
 #pragma unroll
             for (int j = 0; j < D_LOADS; ++j) {
                 f32x4 v = rd[j];
-                if (p.dact) {
+                if (p.dact == ACT_ELU) {                  // 1 + min(y, 0)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fminf(ry[j][e], 0.f), v[e]);
+                } else if (p.dact) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(ry[j][e], p.dact);
                 }
@@ -385,38 +396,53 @@ void launch_thin_fwd(ThinFwdParams p, hipStream_t st) {
 //   dX[y][x] = sum_{ky,kx} W[.][ky][kx][.]^T dZ[y + 1 - ky][x + 1 - kx]     (dZ = dY * act'(Y), zero outside the image)
 //   + the reflection fold: what the mirrored border of the padded input received comes back to row 1 / H-2 and column
 //     1 / W-2.  Those are EXTRA k-steps, not epilogue work: row 1 also multiplies dZ row 0 by the ky = 0 taps (row H-2:
-//     dZ row H-1, ky = 2) -- the whole stage, a uniform branch; column 1 also multiplies dZ column 0 by the kx = 0 taps
-//     (column W-2: column W-1, kx = 2) -- one lane of one edge tile, every other lane of that tile reads the ring's zero
-//     halo entry instead.
+//     dZ row H-1, ky = 2) -- extra k-steps of the whole stage, a uniform branch; column 1 also receives dZ column 0
+//     through the kx = 0 taps (column W-2: column W-1, kx = 2) -- added to the A operand of that one pixel lane of one
+//     edge tile (every other lane of the tile adds the ring's zero halo entry).
 //   * dZ rows are staged once per workgroup (activation derivative applied there), weights live in registers;
 //   * the 2x2 sum of the upsample gradient is two rows accumulated into the same accumulators plus an in-lane add of
 //     register pairs (the 16x16 C/D map keeps 4 consecutive pixels in a lane): plain stores, no atomics.
 struct ThinDgradParams {
-    const float* dy;     // [B,H,W,16]
+    const float* dy;     // [B,H,W,CK]
     const float* y;      // forward output or NULL
-    const float* wt;     // packed [Cin][9][16] (dvs_conv2d_pack_wt)
-    float* dx;           // [B,H,W,NOUT], or [B,H/2,W/2,16] when UP
-    int B, H, W, dact;
-    int nseg, rows_per_wg, row_chunks;
+    const float* wt;     // packed [nout][9][CK] (dvs_conv2d_pack_wt)
+    float* dx;           // [B,H,W,nout] (C1 == 0), or the coarse [B,H/2,W/2,C1] tensor of an upsample(+concat) input
+    float* dx_skip;      // [B,H,W,nout-C1]: the skip tensor's gradient (C1 < nout), or NULL
+    int B, H, W, dact, nout, C1;
+    int nseg, rows_per_wg, row_chunks, nsplit;
 };
 
-template <int NOUT, int SEG, bool UP>
-__global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
-    constexpr int CK = 16, CS = CK + 2, C4 = CK / 4;
+// CK = channels of dY (the forward's Cout: 16 / 32); a workgroup computes 16 NTN of the nout input channels (split index
+// from the block id: weights for more than 32 channels do not fit a wave's registers, and dZ rows are cheap to re-stage);
+// channels below C1 belong to the upsampled operand (2x2-summed), the rest to the skip tensor / the plain input.
+template <int CK, int NTN, int SEG>
+__device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
+    constexpr int CS = CK + 2, C4 = CK / 4;
     constexpr int COLS = SEG + 2, ROWF = COLS * CS;
     constexpr int ROW_VECS = COLS * C4, X_LOADS = (ROW_VECS + NT - 1) / NT;
-    constexpr int PXW = SEG / 4, PT = PXW / 16, NTN = NOUT / 16;
-    static_assert(PXW % 16 == 0 && (!UP || NOUT == 16), "shape");
+    constexpr int PXW = SEG / 4, PT = PXW / 16;
+    static_assert(PXW % 16 == 0, "shape");
     __shared__ __attribute__((aligned(16))) float Ps[4 * ROWF];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lg = xcd_logical(blockIdx.x, gridDim.x, 1);
+    const int split = lg % p.nsplit;                      // the channel groups of one pixel column are neighbours: shared dZ rows
+    lg /= p.nsplit;
     const int chunk = lg % p.row_chunks;
     lg /= p.row_chunks;
     const int seg = lg % p.nseg, b = lg / p.nseg;
     const int iy_begin = chunk * p.rows_per_wg, iy_end = min(p.H, iy_begin + p.rows_per_wg);
     const int x0 = seg * SEG;
+    const int n_base = split * 16 * NTN;
+    bool coarse[NTN];                                     // per 16-channel tile, workgroup-uniform
+    bool any_coarse = false, any_direct = false;
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        coarse[nt] = n_base + nt * 16 < p.C1;
+        any_coarse = any_coarse || coarse[nt];
+        any_direct = any_direct || !coarse[nt];
+    }
 
     // ---- dZ row staging: entry e of a ring row is image column x0 - 1 + e; columns / rows outside the image are zeros
     int x_goff[X_LOADS], x_loff[X_LOADS];
@@ -433,6 +459,7 @@ __global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
     }
     f32x4 rd[X_LOADS], ry[X_LOADS];
     bool row_in = false;
+    const bool elu = p.dact == ACT_ELU;
     auto load_row = [&](int d) {                          // dZ row d (may be -1 or H: zeros)
         row_in = (unsigned)d < (unsigned)p.H;
         const size_t ro = ((size_t)b * p.H + clampi(d, p.H)) * p.W * CK;
@@ -451,7 +478,8 @@ __global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
                 const bool in = row_in && x_in[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = p.dact ? v[e] * act_grad_from_out(ry[j][e], p.dact) : v[e];
+                    // ELU'(y) = 1 + min(y, 0): two instructions, no branch (the generic form is a switch per element)
+                    const float g = elu ? fmaf(v[e], fminf(ry[j][e], 0.f), v[e]) : (p.dact ? v[e] * act_grad_from_out(ry[j][e], p.dact) : v[e]);
                     v[e] = in ? g : 0.f;
                 }
                 float2* d2 = reinterpret_cast<float2*>(dst + x_loff[j]);
@@ -460,14 +488,14 @@ __global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
             }
     };
 
-    // ---- B operand: lane (n = lane & 15 [+ 16 nt], kidx) holds W[co = 4 c4 + kidx][tap][ci = n] = wt[(ci * 9 + tap) * 16 + co]
+    // ---- B operand: lane (n = lane & 15 [+ 16 nt], kidx) holds W[co = 4 c4 + kidx][tap][ci] = wt[(ci * 9 + tap) * CK + co]
     const int n = lane & 15, kidx = lane >> 4;
     float wreg[NTN][9 * C4];
 #pragma unroll
     for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
         for (int s = 0; s < 9 * C4; ++s)
-            wreg[nt][s] = p.wt[((size_t)(nt * 16 + n) * 9 + s / C4) * CK + (s % C4) * 4 + kidx];
+            wreg[nt][s] = p.wt[((size_t)(n_base + nt * 16 + n) * 9 + s / C4) * CK + (s % C4) * 4 + kidx];
     const int a_lane = (wave * PXW + n) * CS + kidx;       // + (16 t + 2 - kx) CS: entry of pixel (lane & 15) of tile t, tap kx
     // column fold: the one lane whose pixel is image column 1 (first segment, wave 0, tile 0) / W - 2 (last segment, last
     // wave, last tile) reads entry 1 (column 0) / SEG (column W - 1); the other lanes of that tile read the zero halo entry
@@ -495,96 +523,128 @@ __global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
     for (int iy = iy_begin; iy < iy_end; ++iy) {
         const bool more = iy + 1 < iy_end;
         if (more) load_row(iy + 2);
-        auto taps = [&](const float* row, int ky) {       // the three kx taps of weight row ky on one dZ row of the ring
+        // operands of one tap (all k-steps, all pixel tiles) / its MFMAs.  The LDS reads of tap i + 1 are issued before the
+        // MFMAs of tap i and fenced there (sched_barrier): left alone, the scheduler sinks every ds_read next to its MFMA and
+        // the wave pays one LDS round trip per k-step.
+        auto lda = [&](float (&a)[PT][C4], const float* row, int kx) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int t = 0; t < PT; ++t)
 #pragma unroll
-                for (int c4 = 0; c4 < C4; ++c4) {
+                for (int c4 = 0; c4 < C4; ++c4) a[t][c4] = row[a_lane + (t * 16 + 2 - kx) * CS + c4 * 4];
+            // column fold (edge tiles, wave-uniform): image column 1 also receives dZ column 0 through the kx = 0 taps, column
+            // W - 2 receives column W - 1 through kx = 2 -- added to the OPERAND of that one pixel lane (the other lanes add
+            // the ring's zero halo entry), not multiplied separately
+            if (kx == 0 && edge_l) {
 #pragma unroll
-                    for (int t = 0; t < PT; ++t) {
-                        const float a = row[a_lane + (t * 16 + 2 - kx) * CS + c4 * 4];
-#pragma unroll
-                        for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = mma(a, wreg[nt][(ky * 3 + kx) * C4 + c4], acc[t][nt]);
-                    }
-                }
-        };
-        auto col_fold = [&](const float* row, int ky) {   // edge tiles only: kx = 0 on column 0 / kx = 2 on column W - 1
-            if (edge_l) {
-#pragma unroll
-                for (int c4 = 0; c4 < C4; ++c4) {
-                    const float a = row[fold_l + c4 * 4];
-#pragma unroll
-                    for (int nt = 0; nt < NTN; ++nt) acc[0][nt] = mma(a, wreg[nt][(ky * 3 + 0) * C4 + c4], acc[0][nt]);
-                }
+                for (int c4 = 0; c4 < C4; ++c4) a[0][c4] += row[fold_l + c4 * 4];
             }
-            if (edge_r) {
+            if (kx == 2 && edge_r) {
 #pragma unroll
-                for (int c4 = 0; c4 < C4; ++c4) {
-                    const float a = row[fold_r + c4 * 4];
-#pragma unroll
-                    for (int nt = 0; nt < NTN; ++nt) acc[PT - 1][nt] = mma(a, wreg[nt][(ky * 3 + 2) * C4 + c4], acc[PT - 1][nt]);
-                }
+                for (int c4 = 0; c4 < C4; ++c4) a[PT - 1][c4] += row[fold_r + c4 * 4];
             }
         };
+        auto mfmas = [&](const float (&a)[PT][C4], int tap) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const float* row = Ps + ((iy + 2 - ky) & 3) * ROWF;      // dZ row iy + 1 - ky lives in slot (d + 1) & 3
-            taps(row, ky);
-            col_fold(row, ky);
-        }
+            for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                for (int t = 0; t < PT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = mma(a[t][c4], wreg[nt][tap * C4 + c4], acc[t][nt]);
+        };
+        auto taps = [&](const float* row, int ky) {       // the three kx taps of weight row ky on one dZ row (fold rows only)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float a[PT][C4];
+                lda(a, row, kx);
+                mfmas(a, ky * 3 + kx);
+            }
+        };
+        const float* rows[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rows[ky] = Ps + ((iy + 2 - ky) & 3) * ROWF;   // dZ row iy + 1 - ky lives in slot (d + 1) & 3
+        float abuf[2][PT][C4];
+        lda(abuf[0], rows[0], 0);
+        static_for_thin<0, 9>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I + 1 < 9) lda(abuf[(I + 1) & 1], rows[(I + 1) / 3], (I + 1) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(abuf[I & 1], I);
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (iy == 1) {                                    // + what padded row 0 received: dZ row 0 through the ky = 0 taps
             const float* row = Ps + 1 * ROWF;
             taps(row, 0);
-            col_fold(row, 0);
         }
         if (iy == p.H - 2) {                              // + padded row H + 1: dZ row H - 1 through the ky = 2 taps
             const float* row = Ps + (p.H & 3) * ROWF;
             taps(row, 2);
-            col_fold(row, 2);
         }
         // C/D map: pixel = 4 (lane >> 4) + r, channel = lane & 15
-        if (UP) {
-            if (iy & 1) {                                 // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
-                float* orow = p.dx + (((size_t)b * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + ((x0 + wave * PXW + 4 * kidx) >> 1)) * 16 + n;
+        if (any_coarse && (iy & 1)) {                     // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
+            float* orow = p.dx + (((size_t)b * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + ((x0 + wave * PXW + 4 * kidx) >> 1)) * p.C1 +
+                          n_base + n;
 #pragma unroll
-                for (int t = 0; t < PT; ++t) {
-                    orow[(t * 8 + 0) * 16] = acc[t][0][0] + acc[t][0][1];
-                    orow[(t * 8 + 1) * 16] = acc[t][0][2] + acc[t][0][3];
+            for (int nt = 0; nt < NTN; ++nt)
+                if (coarse[nt]) {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        orow[(size_t)(t * 8 + 0) * p.C1 + nt * 16] = acc[t][nt][0] + acc[t][nt][1];
+                        orow[(size_t)(t * 8 + 1) * p.C1 + nt * 16] = acc[t][nt][2] + acc[t][nt][3];
+                        acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
-                zero_acc();
-            }
-        } else {
-            float* orow = p.dx + (((size_t)b * p.H + iy) * p.W + x0 + wave * PXW + 4 * kidx) * NOUT + n;
+        }
+        if (any_direct) {
+            const int cs = p.nout - p.C1;                 // channels of the tensor these tiles belong to (C1 == 0: the input itself)
+            float* base = p.C1 > 0 ? p.dx_skip : p.dx;
+            float* orow = base + (((size_t)b * p.H + iy) * p.W + x0 + wave * PXW + 4 * kidx) * cs + (n_base - p.C1) + n;
 #pragma unroll
-            for (int t = 0; t < PT; ++t)
+            for (int nt = 0; nt < NTN; ++nt)
+                if (!coarse[nt]) {
 #pragma unroll
-                for (int nt = 0; nt < NTN; ++nt)
+                    for (int t = 0; t < PT; ++t) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) orow[(t * 16 + r) * NOUT + nt * 16] = acc[t][nt][r];
-            zero_acc();
+                        for (int r = 0; r < 4; ++r) orow[(size_t)(t * 16 + r) * cs + nt * 16] = acc[t][nt][r];
+                        acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
         }
         if (more) store_row(iy + 2);
         __syncthreads();
     }
 }
 
-template <int NOUT, int SEG, bool UP>
+template <int CK, int NTN, int SEG>
+__global__ __launch_bounds__(NT) void thin_dgrad_kernel(ThinDgradParams p) {
+    thin_dgrad_body<CK, NTN, SEG>(p);
+}
+// 48 input channels per workgroup keep 216 weight values per lane: one wave per SIMD with the whole register file (the
+// register allocator otherwise squeezes under 256 VGPRs by re-reading every LDS operand right before its MFMA)
+template <int CK, int NTN, int SEG>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void thin_dgrad_kernel_w1(ThinDgradParams p) {
+    thin_dgrad_body<CK, NTN, SEG>(p);
+}
+
+template <int CK, int NTN, int SEG, bool W1 = false>
 void launch_thin_dgrad(ThinDgradParams p, hipStream_t st) {
+    auto kern = W1 ? thin_dgrad_kernel_w1<CK, NTN, SEG> : thin_dgrad_kernel<CK, NTN, SEG>;
     p.nseg = p.W / SEG;
+    p.nsplit = p.nout / (16 * NTN);
     static const int slots = [] {
         int occ = 0, dev = 0, cus = 256;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, thin_dgrad_kernel<NOUT, SEG, UP>, NT, 0) != hipSuccess || occ < 1) occ = 1;
+        auto k = W1 ? thin_dgrad_kernel_w1<CK, NTN, SEG> : thin_dgrad_kernel<CK, NTN, SEG>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, NT, 0) != hipSuccess || occ < 1) occ = 1;
         return cus * occ;
     }();
-    const int cols = p.B * p.nseg;
+    const int cols = p.B * p.nseg * p.nsplit;
     int chunks = max(1, min(slots / cols, p.H / 8));
     p.rows_per_wg = ((p.H + chunks - 1) / chunks + 1) & ~1;   // even: a 2x2 block never straddles two workgroups
     p.row_chunks = (p.H + p.rows_per_wg - 1) / p.rows_per_wg;
     dvs::ProfScope prof(dvs::SLOT_CONV_DGRAD, st);
-    prof.work(2.0 * p.B * p.H * p.W * 16 * 9.0 * NOUT);
-    hipLaunchKernelGGL((thin_dgrad_kernel<NOUT, SEG, UP>), dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
+    prof.work(2.0 * p.B * p.H * p.W * CK * 9.0 * p.nout);
+    hipLaunchKernelGGL(kern, dim3(cols * p.row_chunks), dim3(NT), 0, st, p);
 }
 
 }  // namespace
@@ -632,15 +692,19 @@ bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const
 
 namespace dvsconv {
 
-// arguments as dvs_conv2d_dgrad receives them: H, W, Cin = the forward conv's (logical, full-resolution) input, Cout = 16
+// arguments as dvs_conv2d_dgrad receives them: H, W, Cin = the forward conv's (logical, full-resolution) input
 bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out, int dact, int B, int H, int W, int Cin,
                 int Cout, int split_c1, float* dx_skip, hipStream_t st) {
     static const bool enabled = [] { const char* e = getenv("DVS_CONV_THIN"); return !(e && e[0] == '0'); }();
-    if (!enabled || Cout != 16 || H < 8 || dx_skip) return false;
+    if (!enabled || H < 8) return false;
+    if (split_c1 > 0 && (((H | W) & 1) || (split_c1 < Cin && !dx_skip))) return false;
     ThinDgradParams p{};
-    p.dy = dy; p.y = y_out; p.wt = wt; p.dx = dx; p.B = B; p.H = H; p.W = W; p.dact = dact;
-    if (split_c1 == 16 && Cin == 16 && W % 128 == 0 && !((H | W) & 1)) launch_thin_dgrad<16, 128, true>(p, st);
-    else if (split_c1 == 0 && Cin == 32 && W % 64 == 0) launch_thin_dgrad<32, 64, false>(p, st);
+    p.dy = dy; p.y = y_out; p.wt = wt; p.dx = dx; p.dx_skip = dx_skip; p.B = B; p.H = H; p.W = W; p.dact = dact;
+    p.nout = Cin; p.C1 = split_c1;
+    if (Cout == 16 && Cin == 16 && split_c1 == 16 && W % 128 == 0) launch_thin_dgrad<16, 1, 128>(p, st);            // upconv_0_1
+    else if (Cout == 16 && Cin == 32 && split_c1 == 0 && W % 64 == 0) launch_thin_dgrad<16, 2, 64>(p, st);          // upconv_0_0
+    else if (Cout == 32 && Cin % 48 == 0 && Cin <= 192 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1
+    else if (Cout == 32 && Cin % 32 == 0 && Cin <= 128 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 2, 64>(p, st);
     else return false;
     return true;
 }

@@ -60,7 +60,7 @@ def test_conv_fwd_bwd(gpu_device, case):
         assert relmax(a, r) < 1e-4, (nm, relmax(a, r))
 
 
-@pytest.mark.parametrize("c1,c2,co,H,W", [(32, 64, 32, 24, 40), (256, 256, 128, 10, 14), (32, 64, 32, 26, 96)])
+@pytest.mark.parametrize("c1,c2,co,H,W", [(32, 64, 32, 24, 40), (256, 256, 128, 10, 14), (32, 64, 32, 26, 96), (32, 64, 32, 20, 128)])
 def test_upsample_concat_conv(gpu_device, c1, c2, co, H, W):
     """upsample(x) ; cat([x, skip]) ; ConvBlock (model/depthnet.py:79-88) as one call."""
     from deep_visual_slam_amd import conv as DC
