@@ -1,5 +1,7 @@
-// a2 backward: weight gradient of the decoder's thin full-resolution layers (Cout = 16 / 32; upconv_1_0, _1_1, _0_0,
-// _0_1 of model/depthnet.py:49-62 -- ReflectionPad2d(1) + 3x3 conv + ELU on 120x160 ... 480x640 maps).
+// a2: row-ring kernels for the depth decoder's thin full-resolution layers (16 / 32 output channels: upconv_1_0, _1_1,
+// _0_0, _0_1 of model/depthnet.py:49-62 -- ReflectionPad2d(1) + 3x3 conv + ELU on 120x160 ... 480x640 maps; the fused
+// layers.py:106-136 ConvBlock / Conv3x3 with the upsample + concat of depthnet.py:79-85 in front).  Three kernels, one
+// structure: thin_wgrad_kernel, thin_fwd_kernel, thin_dgrad_kernel.  First the weight gradient:
 //
 //   dW[co][ky][kx][ci] = sum_{b,y,x} dZ[b,y,x,co] * X[b, refl(y+ky-1), refl(x+kx-1), ci],   dZ = dY * ELU'(Y)
 //
