@@ -306,18 +306,20 @@ __device__ __attribute__((aligned(16))) float g_dvs_zero_page_w[4] = {0.f, 0.f, 
 // stage's per-row work is a ds_read_b64 plus two bounds compares, one add, one 64-bit shift-add and two selects
 // (~10 VALU instead of ~40 of incremental coordinate updates + padding arithmetic).  Zero padding, NHWC input only:
 // the encoder convolutions, which are all this kernel serves.
-constexpr int PT = 256;          // pixels per half of the pixel ring (8 stages)
+constexpr int PT = 256;          // pixels per half of the pixel ring (8 or 16 stages)
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int BPD>
 __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int D_INS = BM / 32, X_INS = BN / 32;          // DMA instructions per wave per stage
+    constexpr int D_INS = BM * BPD / 1024, X_INS = BN * BPD / 1024;   // DMA instructions (1 KB each) per wave per stage
+    constexpr int SPR = PT / BPD;                            // stages per ring half
+    static_assert(D_INS >= 1 && X_INS >= 1 && (SPR & (SPR - 1)) == 0, "stage shape");
     constexpr int DV = BM / 4, XV = BN / 4;                  // 16-byte slots per pixel row
     constexpr int D_RPI = 64 / DV, X_RPI = 64 / XV;          // pixel rows per instruction
     static_assert(WM * WN == 4 && DV <= 64 && XV <= 64, "tile");
     static_assert(MODE == IN_NHWC, "plain NHWC input");
-    __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
-    __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+    __shared__ __attribute__((aligned(16))) float Ds[2][BPD][BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BPD][BN];
     __shared__ int2 ptab[2][PT];                             // .x: offset of the window origin, .y: y0 << 16 | x0 & 0xffff
 
     const ConvShape& s = p.s;
@@ -407,13 +409,13 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     __syncthreads();
     int buf = 0, stage = 0;
 #pragma unroll 1
-    for (int mb = m_begin; mb < m_end; mb += BP, ++stage) {
+    for (int mb = m_begin; mb < m_end; mb += BPD, ++stage) {
         // refill the half of the ring that the stages issued from now on no longer touch: at stage 8q (q >= 1) the
         // next issue reads pixels of stage 8q+1, which live in half q & 1; half (q-1) & 1 ... is the one to reuse
-        if ((stage & 7) == 0 && stage > 0) fill_ring(((stage >> 3) + 1) & 1, m_begin + ((stage >> 3) + 1) * PT);
-        if (!p.dbg && mb + BP < m_end) issue_stage(mb + BP, buf ^ 1);
+        if ((stage & (SPR - 1)) == 0 && stage > 0) fill_ring(((stage / SPR) + 1) & 1, m_begin + ((stage / SPR) + 1) * PT);
+        if (!p.dbg && mb + BPD < m_end) issue_stage(mb + BPD, buf ^ 1);
 #pragma unroll
-        for (int t = 0; t < BP / 2; ++t) {
+        for (int t = 0; t < BPD / 2; ++t) {
             float a[TM], b[TN];
 #pragma unroll
             for (int m = 0; m < TM; ++m) a[m] = Ds[buf][2 * t + h][a_col + m * 32];
@@ -449,7 +451,8 @@ template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(WgradParams p, hipStream_t st) {
     const int M = p.s.B * p.s.Ho * p.s.Wo;
     const int tiles = ((p.s.Cout + BM - 1) / BM) * ((p.s.Ktot + BN - 1) / BN);
-    int splits = (1024 + tiles - 1) / tiles;                 // ~4 workgroups per CU in flight
+    static const int wg_target = [] { const char* e = getenv("DVS_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
+    int splits = (wg_target + tiles - 1) / tiles;            // ~4 workgroups per CU in flight
     splits = max(1, min(splits, (M + 255) / 256));           // at least 8 stages per workgroup
     int mps = ((M + splits - 1) / splits + BP - 1) / BP * BP;
     splits = (M + mps - 1) / mps;
@@ -466,7 +469,16 @@ void launch_cfg(WgradParams p, hipStream_t st) {
         p.dbg = dbg & 4;
         if (dma && MODE == IN_NHWC && p.s.pad_mode == PAD_ZERO && p.t.dact == 0 && p.dbias == nullptr && p.s.kh * p.s.kw <= 30 &&
             (double)p.s.B * p.s.H * p.s.W * p.s.Cin < 536870912.0 && (double)M * p.s.Cout < 536870912.0) {
-            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+            // 16-pixel stages: half the LDS of 32-pixel ones, so four workgroups per CU instead of two hide each other's
+            // vmcnt(0) + barrier at the end of a stage (83 -> 87 TF over the step's launches; DVS_WGRAD_BP=32 for the old shape)
+            static const int bpd = [] { const char* e = getenv("DVS_WGRAD_BP"); return e ? atoi(e) : 16; }();
+            if constexpr (BM >= 64) {
+                if (bpd == 16) {
+                    hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC, 16>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC, 32>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
             return;
         }
     }
