@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
 MAX_SCALES = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp = C.c_void_p
 
@@ -60,11 +60,11 @@ _SIGNATURES = {
     "dvs_conv2d_head_bwd": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp]),
     "dvs_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
-    "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
-    "dvs_bn_apply_fwd": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, C.c_int, _vp]),
-    "dvs_bn_bwd_workspace": (C.c_size_t, [C.c_size_t, C.c_int]),
-    "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, _vp]),
-    "dvs_bn_bwd_apply": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "dvs_bn_apply_fwd": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_bn_bwd_workspace": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
+    "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),
+    "dvs_bn_bwd_apply": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),

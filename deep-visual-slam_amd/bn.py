@@ -12,10 +12,12 @@ from ._lib import check, ptr
 CL = torch.channels_last
 
 
-def _finalize(stats, count, bn, out):
-    """stats [2][C] (sum, sum of squares) -> out [4][C] = scale, shift, mean, invstd; running statistics and
-    num_batches_tracked updated as nn.BatchNorm2d does in training mode."""
+def _finalize_groups(stats, count, bn, groups):
+    """stats [G][2][C] (sum, sum of squares per sub-batch) -> [G][4][C] = scale, shift, mean, invstd, one launch;
+    running statistics and num_batches_tracked are updated as G successive forward calls of nn.BatchNorm2d in
+    training mode would have done."""
     C = stats.shape[-1]
+    out = torch.empty(groups, 4, C, device=stats.device, dtype=torch.float32)
     train_stats = bn.training and bn.track_running_stats
     nbt = bn.num_batches_tracked if train_stats else None
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
@@ -24,18 +26,8 @@ def _finalize(stats, count, bn, out):
                                      ptr(bn.running_mean) if train_stats else None,
                                      ptr(bn.running_var) if train_stats else None,
                                      float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps),
-                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), C,
-                                     nbt.data_ptr() if nbt is not None else None, _lib.stream()), "dvs_bn_finalize")
-
-
-def _finalize_groups(stats, count, bn, groups):
-    """[G][4][C]; the groups are finalised in order, i.e. the running statistics see G successive updates -- what G
-    separate forward calls of the module would have done."""
-    C = stats.shape[-1]
-    out = torch.empty(groups, 4, C, device=stats.device, dtype=torch.float32)
-    st = stats.view(groups, 2, C)
-    for g in range(groups):
-        _finalize(st[g], count, bn, out[g])
+                                     out[0, 0].data_ptr(), out[0, 1].data_ptr(), out[0, 2].data_ptr(), out[0, 3].data_ptr(), C,
+                                     nbt.data_ptr() if nbt is not None else None, groups, _lib.stream()), "dvs_bn_finalize")
     return out
 
 
@@ -48,14 +40,12 @@ class _BNAct(torch.autograd.Function):
         B, C, H, W = y.shape
         M = B * H * W // groups                       # rows per group
         z = torch.empty_like(y)
-        st = _lib.stream()
-        for g in range(groups):
-            o = 4 * g * M * C                         # byte offset of the group's rows (batch is the outermost dim)
-            r_sc = res_fin[g, 0].data_ptr() if res_fin is not None else None
-            r_sh = res_fin[g, 1].data_ptr() if res_fin is not None else None
-            check(l.dvs_bn_apply_fwd(y.data_ptr() + o, fin[g, 0].data_ptr(), fin[g, 1].data_ptr(),
-                                     residual.data_ptr() + o if residual is not None else None, r_sc, r_sh,
-                                     z.data_ptr() + o, M, C, int(relu), st), "dvs_bn_apply_fwd")
+        # one launch for all groups: group g = rows [g M, (g + 1) M) with row g of the [G][4][C] parameter tables
+        check(l.dvs_bn_apply_fwd(y.data_ptr(), fin[0, 0].data_ptr(), fin[0, 1].data_ptr(),
+                                 residual.data_ptr() if residual is not None else None,
+                                 res_fin[0, 0].data_ptr() if res_fin is not None else None,
+                                 res_fin[0, 1].data_ptr() if res_fin is not None else None,
+                                 z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_apply_fwd")
         ctx.relu, ctx.groups = relu, groups
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
         ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
@@ -75,7 +65,7 @@ class _BNAct(torch.autograd.Function):
         dy = torch.empty_like(y)
         pooled = gamma.grad is not None
         sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
-        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C) // 4, device=y.device, dtype=torch.float32)
+        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
         g_par, b_par, rg_par, rb_par = ctx.affine
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
@@ -89,22 +79,20 @@ class _BNAct(torch.autograd.Function):
             rsums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
             rgs, rbs = gradsink.target(rg_par), gradsink.target(rb_par)
             rsunk = rgs is not None and rbs is not None
-        for g in range(G):
-            o = 4 * g * M * C
-            check(l.dvs_bn_bwd_reduce(dz.data_ptr() + o, z.data_ptr() + o if ctx.relu else None, y.data_ptr() + o,
-                                      fin[g, 2].data_ptr(), fin[g, 3].data_ptr(), du.data_ptr() + o if need_du else None,
-                                      sums[g].data_ptr(), ptr(ws), M, C, st), "dvs_bn_bwd_reduce")
-            check(l.dvs_bn_bwd_apply(du.data_ptr() + o, y.data_ptr() + o, fin[g, 2].data_ptr(), fin[g, 3].data_ptr(),
-                                     ptr(gamma), sums[g].data_ptr(), dy.data_ptr() + o, M, C, ptr(gs) if sunk else None,
-                                     ptr(bs) if sunk else None, st), "dvs_bn_bwd_apply")
-            if ds_res:
-                check(l.dvs_bn_bwd_reduce(du.data_ptr() + o, None, residual.data_ptr() + o, res_fin[g, 2].data_ptr(),
-                                          res_fin[g, 3].data_ptr(), None, rsums[g].data_ptr(), ptr(ws), M, C, st),
-                      "dvs_bn_bwd_reduce")
-                check(l.dvs_bn_bwd_apply(du.data_ptr() + o, residual.data_ptr() + o, res_fin[g, 2].data_ptr(),
-                                         res_fin[g, 3].data_ptr(), ptr(res_gamma), rsums[g].data_ptr(),
-                                         d_res.data_ptr() + o, M, C, ptr(rgs) if rsunk else None,
-                                         ptr(rbs) if rsunk else None, st), "dvs_bn_bwd_apply")
+        check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(),
+                                  fin[0, 2].data_ptr(), fin[0, 3].data_ptr(), du.data_ptr() if need_du else None,
+                                  sums.data_ptr(), ptr(ws), M, C, G, st), "dvs_bn_bwd_reduce")
+        check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
+                                 ptr(gamma), sums.data_ptr(), dy.data_ptr(), M, C, ptr(gs) if sunk else None,
+                                 ptr(bs) if sunk else None, G, st), "dvs_bn_bwd_apply")
+        if ds_res:
+            check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[0, 2].data_ptr(),
+                                      res_fin[0, 3].data_ptr(), None, rsums.data_ptr(), ptr(ws), M, C, G, st),
+                  "dvs_bn_bwd_reduce")
+            check(l.dvs_bn_bwd_apply(du.data_ptr(), residual.data_ptr(), res_fin[0, 2].data_ptr(),
+                                     res_fin[0, 3].data_ptr(), ptr(res_gamma), rsums.data_ptr(),
+                                     d_res.data_ptr(), M, C, ptr(rgs) if rsunk else None,
+                                     ptr(rbs) if rsunk else None, G, st), "dvs_bn_bwd_apply")
         d_gamma = d_beta = d_rg = d_rb = None
         if not sunk:
             d_gamma, d_beta = (sums[0, 1], sums[0, 0]) if G == 1 else (sums[:, 1].sum(0), sums[:, 0].sum(0))

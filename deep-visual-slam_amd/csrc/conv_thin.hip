@@ -705,7 +705,8 @@ bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out,
     p.nout = Cin; p.C1 = split_c1;
     if (Cout == 16 && Cin == 16 && split_c1 == 16 && W % 128 == 0) launch_thin_dgrad<16, 1, 128>(p, st);            // upconv_0_1
     else if (Cout == 16 && Cin == 32 && split_c1 == 0 && W % 64 == 0) launch_thin_dgrad<16, 2, 64>(p, st);          // upconv_0_0
-    else if (Cout == 32 && Cin % 48 == 0 && Cin <= 192 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1
+    else if (Cout == 32 && Cin % 48 == 0 && Cin <= 192 && split_c1 % 16 == 0 && W % 64 == 0)
+        launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1
     else if (Cout == 32 && Cin % 32 == 0 && Cin <= 128 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 2, 64>(p, st);
     else return false;
     return true;

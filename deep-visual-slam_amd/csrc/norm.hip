@@ -16,26 +16,36 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int NT = 256;
 
+// groups > 1: stats is [G][2][C], the outputs are rows of a [G][4][C] table (scale, shift, mean, invstd); the running
+// statistics receive the G momentum updates in order -- what G successive forward calls of the module would have done.
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-                                   float* __restrict__ invstd_out, int C, long long* __restrict__ num_batches_tracked) {
+                                   float* __restrict__ invstd_out, int C, long long* __restrict__ num_batches_tracked,
+                                   int groups) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    float mean = stats[c] / count;
-    float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);     // biased, as used for normalisation
-    float invstd = rsqrtf(var + eps);
-    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    scale[c] = g * invstd;
-    shift[c] = b - mean * g * invstd;
-    mean_out[c] = mean;
-    invstd_out[c] = invstd;
-    if (running_mean) {
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += groups;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
+    for (int grp = 0; grp < groups; ++grp) {
+        const float* st = stats + (size_t)grp * 2 * C;
+        const size_t o = (size_t)grp * 4 * C + c;
+        float mean = st[c] / count;
+        float var = fmaxf(st[C + c] / count - mean * mean, 0.f);     // biased, as used for normalisation
+        float invstd = rsqrtf(var + eps);
+        scale[o] = g * invstd;
+        shift[o] = b - mean * g * invstd;
+        mean_out[o] = mean;
+        invstd_out[o] = invstd;
         float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+    if (running_mean) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
     }
 }
 
@@ -44,6 +54,12 @@ __global__ __launch_bounds__(NT) void bn_apply_fwd_kernel(const float* __restric
                                                           const float* __restrict__ sh, const float* __restrict__ r,
                                                           const float* __restrict__ rsc, const float* __restrict__ rsh,
                                                           float* __restrict__ z, size_t n4, int C, int relu) {
+    {   // blockIdx.y = group: n4 vectors of rows per group, parameter rows 4C floats apart
+        const size_t go = (size_t)blockIdx.y * n4 * 4, po = (size_t)blockIdx.y * 4 * C;
+        y += go; z += go; sc += po; sh += po;
+        if (r) r += go;
+        if (rsc) { rsc += po; rsh += po; }
+    }
     size_t stride = (size_t)gridDim.x * NT;
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
         int c = (int)((i * 4) % C);
@@ -75,6 +91,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
                                                            const float* __restrict__ invstd, float* __restrict__ du_out,
                                                            float* __restrict__ sums, int M, int C, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
+    {   // blockIdx.y = group: M rows each; the partial rows of group g follow those of group g - 1
+        const size_t go = (size_t)blockIdx.y * M * C, po = (size_t)blockIdx.y * 4 * C;
+        dz += go; y += go; mean += po; invstd += po;
+        if (z) z += go;
+        if (du_out) du_out += go;
+        sums += (size_t)blockIdx.y * gridDim.x * 2 * C;
+    }
     const int cv = C / 4, tid = threadIdx.x;
     const int rl = tid / cv, c = (tid % cv) * 4, rlanes = NT / cv;     // cv = C/4 divides 256 (host-checked)
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -141,6 +164,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_sum_partials_kernel(const float* __
                                                                  int rows, int C2, int rows_per_slice) {
     int j = blockIdx.x * NT + threadIdx.x;
     if (j >= C2) return;
+    partials += (size_t)blockIdx.z * rows * C2;         // blockIdx.z = group
+    sums += (size_t)blockIdx.z * C2;
     int r0 = blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int r = r0;
@@ -160,10 +185,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
                                                           float* __restrict__ dy, size_t n4, int C, float inv_count,
                                                           float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+    {   // blockIdx.y = group
+        const size_t go = (size_t)blockIdx.y * n4 * 4, po = (size_t)blockIdx.y * 4 * C;
+        du += go; y += go; dy += go; mean += po; invstd += po;
+        sums += (size_t)blockIdx.y * 2 * C;
+    }
     if (blockIdx.x == 0 && dgamma_acc) {               // gradient sink: d gamma / d beta added straight into .grad
-        for (int c = threadIdx.x; c < C; c += NT) {
-            dbeta_acc[c] += sums[c];
-            dgamma_acc[c] += sums[C + c];
+        for (int c = threadIdx.x; c < C; c += NT) {     // (atomics: the groups of one launch add to the same parameters)
+            atomicAdd(dbeta_acc + c, sums[c]);
+            atomicAdd(dgamma_acc + c, sums[C + c]);
         }
     }
     size_t stride = (size_t)gridDim.x * NT;
@@ -195,24 +225,25 @@ extern "C" {
 
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                    float* invstd, int C, long long* num_batches_tracked, void* stream) {
-    DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1, "dvs_bn_finalize: bad argument");
+                    float* invstd, int C, long long* num_batches_tracked, int groups, void* stream) {
+    DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1 && groups >= 1, "dvs_bn_finalize: bad argument");
     DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_finalize: running stats come together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), stats,
                        (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C,
-                       num_batches_tracked);
+                       num_batches_tracked, groups);
     return dvs::check_launch("dvs_bn_finalize");
 }
 
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
-                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, void* stream) {
-    DVS_REQUIRE(y && scale && shift && z && M > 0 && C > 0 && (C & 3) == 0, "dvs_bn_apply_fwd: bad argument");
+                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, int groups,
+                     void* stream) {
+    DVS_REQUIRE(y && scale && shift && z && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1, "dvs_bn_apply_fwd: bad argument");
     DVS_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual),
                 "dvs_bn_apply_fwd: residual affine needs residual, scale and shift");
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_FWD, st);
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(stream_grid(n4)), dim3(NT), 0, st, y, scale, shift, residual, res_scale,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, y, scale, shift, residual, res_scale,
                        res_shift, z, n4, C, relu);
     return dvs::check_launch("dvs_bn_apply_fwd");
 }
@@ -227,16 +258,16 @@ inline void bn_reduce_geometry(size_t M, int C, int* blocks, int* rpb) {
 }
 }  // namespace
 
-size_t dvs_bn_bwd_workspace(size_t M, int C) {
-    if (M == 0 || C <= 0 || (C & 3) || C / 4 > NT || NT % (C / 4)) return 0;
+size_t dvs_bn_bwd_workspace(size_t M, int C, int groups) {
+    if (M == 0 || C <= 0 || (C & 3) || C / 4 > NT || NT % (C / 4) || groups < 1) return 0;
     int blocks, rpb;
     bn_reduce_geometry(M, C, &blocks, &rpb);
-    return (size_t)blocks * 2 * C * sizeof(float);
+    return (size_t)groups * blocks * 2 * C * sizeof(float);
 }
 
 int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
-                      float* du, float* sums, float* workspace, size_t M, int C, void* stream) {
-    DVS_REQUIRE(dz && y && mean && invstd && sums && workspace && M > 0 && C > 0 && (C & 3) == 0,
+                      float* du, float* sums, float* workspace, size_t M, int C, int groups, void* stream) {
+    DVS_REQUIRE(dz && y && mean && invstd && sums && workspace && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1,
                 "dvs_bn_bwd_reduce: bad argument");
     const int cv = C / 4;
     DVS_REQUIRE(cv <= NT && (NT % cv) == 0, "dvs_bn_bwd_reduce: C/4 must divide 256 (C=%d)", C);
@@ -246,23 +277,24 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
     bn_reduce_geometry(M, C, &blocks, &rpb);
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
                            invstd, du, workspace, (int)M, C, rpb);
     }
     const int slices = blocks >= 64 ? 32 : 1, rps = (blocks + slices - 1) / slices;
-    hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices), dim3(NT), 0, st, workspace, sums, blocks,
+    hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices, groups), dim3(NT), 0, st, workspace, sums, blocks,
                        2 * C, rps);
     return dvs::check_launch("dvs_bn_bwd_reduce");
 }
 
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, void* stream) {
-    DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0, "dvs_bn_bwd_apply: bad argument");
+                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
+                     void* stream) {
+    DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1, "dvs_bn_bwd_apply: bad argument");
     DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_bwd_apply: gradient sinks come together");
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
                        C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
     return dvs::check_launch("dvs_bn_bwd_apply");
 }

@@ -166,19 +166,23 @@ int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, i
  *                  neither, NULL = skip): d gamma += sums1, d beta += sums0, i.e. the parameter gradients are
  *                  accumulated in place (what autograd's AccumulateGrad would do with one more launch each).
  *     M = pixels (rows), C % 4 == 0 and C/4 divides 256 (C in {16..1024}).
+ *     groups G >= 1 (PoseNet evaluates its two frame pairs as one batch, each half normalised on its own): ONE launch
+ *     serves G independent sub-batches of M rows each, stored back to back -- tensors [G*M][C], stats / sums [G][2][C],
+ *     scale / shift / mean / invstd = rows of a [G][4][C] table (pass the group-0 rows); gamma / beta / running
+ *     statistics / gradient sinks are shared (running statistics get the G updates in order).
  * ------------------------------------------------------------------------------------------- */
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
-                    float* invstd, int C, long long* num_batches_tracked, void* stream);
+                    float* invstd, int C, long long* num_batches_tracked, int groups, void* stream);
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
-                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu,
+                     const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, int groups,
                      void* stream);
 /* bytes of the per-workgroup partial-sum workspace of dvs_bn_bwd_reduce (0 = unsupported shape) */
-size_t dvs_bn_bwd_workspace(size_t M, int C);
+size_t dvs_bn_bwd_workspace(size_t M, int C, int groups);
 int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
-                      float* du, float* sums, float* workspace, size_t M, int C, void* stream);
+                      float* du, float* sums, float* workspace, size_t M, int C, int groups, void* stream);
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
-                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc,
+                     const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
