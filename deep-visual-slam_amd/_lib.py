@@ -61,6 +61,8 @@ _SIGNATURES = {
     "dvs_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "dvs_bn_fwd": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                              C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_apply_fwd": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_bwd_workspace": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),

@@ -33,19 +33,25 @@ def _finalize_groups(stats, count, bn, groups):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, res_gamma, res_beta, fin, res_fin, relu, groups):
-        """z = act(bn(y) [+ residual | + bn_r(residual)]); fin / res_fin = [G][scale, shift, mean, invstd].
-        With G = 2 the first and the second half of the batch are normalised with their own statistics."""
+    def forward(ctx, y, gamma, beta, residual, res_gamma, res_beta, stat_args, res_fin, relu, groups):
+        """z = act(bn(y) [+ residual | + bn_r(residual)]) in ONE launch: stat_args = (stats [G][2][C] from the conv
+        epilogue, count, running_mean, running_var, momentum, eps, num_batches_tracked); scale / shift are derived in
+        the kernel, which also leaves fin = [G][scale, shift, mean, invstd] for the backward and updates the running
+        statistics.  res_fin = the downsample branch's own table.  With G = 2 the first and the second half of the
+        batch are normalised with their own statistics."""
         l = _lib.lib()
         B, C, H, W = y.shape
         M = B * H * W // groups                       # rows per group
         z = torch.empty_like(y)
-        # one launch for all groups: group g = rows [g M, (g + 1) M) with row g of the [G][4][C] parameter tables
-        check(l.dvs_bn_apply_fwd(y.data_ptr(), fin[0, 0].data_ptr(), fin[0, 1].data_ptr(),
-                                 residual.data_ptr() if residual is not None else None,
-                                 res_fin[0, 0].data_ptr() if res_fin is not None else None,
-                                 res_fin[0, 1].data_ptr() if res_fin is not None else None,
-                                 z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_apply_fwd")
+        stats, count, rmean, rvar, momentum, eps, nbt = stat_args
+        fin = torch.empty(groups, 4, C, device=y.device, dtype=torch.float32)
+        # group g = rows [g M, (g + 1) M) with row g of the [G][.][C] tables
+        check(l.dvs_bn_fwd(y.data_ptr(), stats.data_ptr(), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+                           float(momentum), float(eps), nbt.data_ptr() if nbt is not None else None, fin.data_ptr(),
+                           residual.data_ptr() if residual is not None else None,
+                           res_fin[0, 0].data_ptr() if res_fin is not None else None,
+                           res_fin[0, 1].data_ptr() if res_fin is not None else None,
+                           z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_fwd")
         ctx.relu, ctx.groups = relu, groups
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
         ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
@@ -118,11 +124,16 @@ def bn_act(y, bn, stats, relu=False, residual=None, res_bn=None, res_stats=None,
         raise _lib.DvsError("bn_act: batch %d does not split into %d groups" % (B, groups))
     count = (B // groups) * H * W
     y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
-    fin = _finalize_groups(stats, count, bn, groups)
+    train_stats = bn.training and bn.track_running_stats
+    nbt = bn.num_batches_tracked if train_stats else None
+    if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+        raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
+    stat_args = (stats, count, bn.running_mean if train_stats else None, bn.running_var if train_stats else None,
+                 bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbt)
     res_fin = None
     if residual is not None:
         residual = residual if residual.is_contiguous(memory_format=CL) else residual.contiguous(memory_format=CL)
         if res_bn is not None:
             res_fin = _finalize_groups(res_stats, count, res_bn, groups)
     return _BNAct.apply(y, bn.weight, bn.bias, residual, res_bn.weight if res_bn is not None else None,
-                        res_bn.bias if res_bn is not None else None, fin, res_fin, relu, groups)
+                        res_bn.bias if res_bn is not None else None, stat_args, res_fin, relu, groups)

@@ -84,6 +84,103 @@ __global__ __launch_bounds__(NT) void bn_apply_fwd_kernel(const float* __restric
     }
 }
 
+// finalize + apply in one launch: every thread derives scale / shift of ITS 4 channels from the raw statistics (its
+// channel vector is the same in every grid-stride iteration because C/4 divides the 256 threads), and the first
+// workgroup also writes the [G][4][C] table the backward needs and updates the running statistics (G updates in order).
+struct BnFusedArgs {
+    const float* stats;      // [G][2][C]
+    const float* gamma;
+    const float* beta;
+    float* running_mean;     // or NULL
+    float* running_var;
+    long long* nbt;          // or NULL
+    float* fin;              // [G][4][C] out: scale, shift, mean, invstd
+    float count, momentum, eps;
+};
+__global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const float* __restrict__ y, const float* __restrict__ r,
+                                                          const float* __restrict__ rsc, const float* __restrict__ rsh,
+                                                          float* __restrict__ z, size_t n4, int C, int relu, int groups) {
+    const int grp = blockIdx.y;
+    const int c = (int)(((size_t)threadIdx.x * 4) % C);
+    if (blockIdx.x == 0 && grp == 0 && threadIdx.x < C / 4) {
+        if (threadIdx.x == 0 && a.nbt) *a.nbt += groups;
+        f32x4 rm = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+        if (a.running_mean) {
+            rm = *reinterpret_cast<const f32x4*>(a.running_mean + c);
+            rv = *reinterpret_cast<const f32x4*>(a.running_var + c);
+        }
+        const f32x4 g = a.gamma ? *reinterpret_cast<const f32x4*>(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 b = a.beta ? *reinterpret_cast<const f32x4*>(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < groups; ++q) {
+            const float* st = a.stats + (size_t)q * 2 * C;
+            float* out = a.fin + (size_t)q * 4 * C;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + c), s1 = *reinterpret_cast<const f32x4*>(st + C + c);
+            f32x4 sc, sh, mu, is;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mu[j] = s0[j] / a.count;
+                const float var = fmaxf(s1[j] / a.count - mu[j] * mu[j], 0.f);
+                is[j] = rsqrtf(var + a.eps);
+                sc[j] = g[j] * is[j];
+                sh[j] = b[j] - mu[j] * g[j] * is[j];
+                const float unbiased = a.count > 1.f ? var * a.count / (a.count - 1.f) : var;
+                rm[j] = (1.f - a.momentum) * rm[j] + a.momentum * mu[j];
+                rv[j] = (1.f - a.momentum) * rv[j] + a.momentum * unbiased;
+            }
+            *reinterpret_cast<f32x4*>(out + c) = sc;
+            *reinterpret_cast<f32x4*>(out + C + c) = sh;
+            *reinterpret_cast<f32x4*>(out + 2 * C + c) = mu;
+            *reinterpret_cast<f32x4*>(out + 3 * C + c) = is;
+        }
+        if (a.running_mean) {
+            *reinterpret_cast<f32x4*>(a.running_mean + c) = rm;
+            *reinterpret_cast<f32x4*>(a.running_var + c) = rv;
+        }
+    }
+    // my channels' folded scale / shift for this group
+    f32x4 s, t;
+    {
+        const float* st = a.stats + (size_t)grp * 2 * C;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + c), s1 = *reinterpret_cast<const f32x4*>(st + C + c);
+        const f32x4 g = a.gamma ? *reinterpret_cast<const f32x4*>(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 b = a.beta ? *reinterpret_cast<const f32x4*>(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mu = s0[j] / a.count;
+            const float var = fmaxf(s1[j] / a.count - mu * mu, 0.f);
+            const float is = rsqrtf(var + a.eps);
+            s[j] = g[j] * is;
+            t[j] = b[j] - mu * g[j] * is;
+        }
+    }
+    f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+    if (rsc) {
+        s2 = *reinterpret_cast<const f32x4*>(rsc + (size_t)grp * 4 * C + c);
+        t2 = *reinterpret_cast<const f32x4*>(rsh + (size_t)grp * 4 * C + c);
+    }
+    const size_t go = (size_t)grp * n4;
+    const f32x4* yv = reinterpret_cast<const f32x4*>(y) + go;
+    const f32x4* rv4 = r ? reinterpret_cast<const f32x4*>(r) + go : nullptr;
+    f32x4* zv = reinterpret_cast<f32x4*>(z) + go;
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = yv[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] * s[j] + t[j];
+        if (rv4) {
+            f32x4 u = rv4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = u[j] * s2[j] + t2[j];
+            v += u;
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        zv[i] = v;
+    }
+}
+
 // Column reduction over pixels.  A workgroup owns rows [blockIdx.x * rows_per_block, ...): lane -> (row lane,
 // 4-channel vector); sums[0][c] += sum du, sums[1][c] += sum du * xhat; optionally writes du.
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
@@ -232,6 +329,24 @@ int dvs_bn_finalize(const float* stats, double count, const float* gamma, const 
                        (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C,
                        num_batches_tracked, groups);
     return dvs::check_launch("dvs_bn_finalize");
+}
+
+int dvs_bn_fwd(const float* y, const float* stats, double count, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
+               float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
+               int C, int relu, int groups, void* stream) {
+    DVS_REQUIRE(y && stats && fin && z && M > 0 && C > 0 && (C & 3) == 0 && count >= 1 && groups >= 1, "dvs_bn_fwd: bad argument");
+    DVS_REQUIRE(C / 4 <= NT && (NT % (C / 4)) == 0, "dvs_bn_fwd: C/4 must divide 256 (C=%d)", C);
+    DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_fwd: running stats come together");
+    DVS_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual),
+                "dvs_bn_fwd: residual affine needs residual, scale and shift");
+    BnFusedArgs a{stats, gamma, beta, running_mean, running_var, num_batches_tracked, fin, (float)count, momentum, eps};
+    size_t n4 = M * C / 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_BN_FWD, st);
+    hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, a, y, residual, res_scale, res_shift,
+                       z, n4, C, relu, groups);
+    return dvs::check_launch("dvs_bn_fwd");
 }
 
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,

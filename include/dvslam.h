@@ -174,6 +174,14 @@ int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, i
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                     float* invstd, int C, long long* num_batches_tracked, int groups, void* stream);
+/* finalize + apply_fwd in ONE launch (what the training forward uses): `stats` [G][2][C] raw sums from the conv epilogue,
+ * `fin` [G][4][C] out (scale, shift, mean, invstd: kept for the backward); residual / res_scale / res_shift as in
+ * dvs_bn_apply_fwd (res_scale / res_shift = group-0 rows of the downsample branch's own [G][4][C] table, produced by
+ * dvs_bn_finalize). */
+int dvs_bn_fwd(const float* y, const float* stats, double count, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
+               float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
+               int C, int relu, int groups, void* stream);
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
                      const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, int groups,
                      void* stream);
