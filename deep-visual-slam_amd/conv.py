@@ -107,6 +107,53 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
     return y
 
 
+_prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape)
+
+
+class PackedWeights:
+    """Data-gradient weight packs ([Cin][kh][kw][Cout]) of a fixed set of convolution weights, refreshed with ONE launch.
+    The weights change once per optimiser step, so dp.FusedAdam owns one of these for its arena and calls repack()
+    right after the Adam kernel; conv2d_dgrad then finds the pack here instead of transposing inside the backward pass
+    (51 launches per step).  A pack is trusted only while the weight's torch version counter is the one it was packed
+    at -- any in-place torch update (load_state_dict, torch.optim) falls back to packing on the fly."""
+
+    def __init__(self, weights):
+        self.weights = [w for w in weights if w.dim() == 4 and w.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0
+                        and w.permute(0, 2, 3, 1).is_contiguous()]
+        self.packs, rows, wg = [], [], 0
+        for w in self.weights:
+            co, ci, kh, kw = w.shape
+            wt = torch.empty(ci * kh * kw * co, device=w.device, dtype=torch.float32)
+            self.packs.append(wt)
+            rows.append([w.data_ptr(), wt.data_ptr(), co | (ci << 32), (kh * kw) | (wg << 32)])
+            wg += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+        self.total_wgs = wg
+        self.table = torch.tensor(rows, dtype=torch.int64, device=self.weights[0].device) if rows else None
+
+    def repack(self):
+        if self.table is None:
+            return
+        check(_lib.lib().dvs_conv2d_pack_wt_batch(self.table.data_ptr(), len(self.weights), self.total_wgs, _lib.stream()),
+              "dvs_conv2d_pack_wt_batch")
+        for w, wt in zip(self.weights, self.packs):
+            _prepacked[w.data_ptr()] = (wt, w._version, tuple(w.shape))
+
+    def release(self):
+        for w in self.weights:
+            _prepacked.pop(w.data_ptr(), None)
+
+
+def _packed_weight(w, weight):
+    """[Cin][kh][kw][Cout] operand of the data gradient: the optimiser's pre-packed copy when it is current, else packed here."""
+    ent = _prepacked.get(w.data_ptr())
+    if ent is not None and ent[1] == weight._version and ent[2] == tuple(weight.shape):
+        return ent[0]
+    Cout, Cin, kh, kw = weight.shape
+    wt = torch.empty(Cin * kh * kw * Cout, device=w.device, dtype=torch.float32)
+    check(_lib.lib().dvs_conv2d_pack_wt(w.data_ptr(), wt.data_ptr(), Cout, Cin, kh, kw, _lib.stream()), "dvs_conv2d_pack_wt")
+    return wt
+
+
 def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0):
     """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
     split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
@@ -116,8 +163,7 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
     w = _nhwc(weight)
     Cout, Cin, kh, kw = weight.shape
     B, _, H, W = x_shape
-    wt = torch.empty(Cin * kh * kw * Cout, device=dy.device, dtype=torch.float32)
-    check(l.dvs_conv2d_pack_wt(w.data_ptr(), wt.data_ptr(), Cout, Cin, kh, kw, _lib.stream()), "dvs_conv2d_pack_wt")
+    wt = _packed_weight(w, weight)
     d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None

@@ -577,9 +577,52 @@ __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ 
     }
 }
 
+// Every data-gradient weight pack of a network in ONE launch (the weights only change at the optimiser step, so
+// dp.FusedAdam repacks them all right after it instead of 51 small launches inside the backward pass).
+struct PackEntry {
+    const float* w;
+    float* wt;
+    int Cout, Cin, T, wg_begin;      // wg_begin: first workgroup of this entry (entries sorted, cumulative)
+};
+__global__ __launch_bounds__(256) void pack_wt_batch_kernel(const PackEntry* __restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    __shared__ int s_e;
+    if (threadIdx.x == 0) {
+        int e = 0;
+        while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].wg_begin) ++e;
+        s_e = e;
+    }
+    __syncthreads();
+    const PackEntry en = tab[s_e];
+    const int tci = (en.Cin + 31) / 32, tco = (en.Cout + 31) / 32;
+    int local = blockIdx.x - en.wg_begin;
+    const int tap = local / (tci * tco);
+    local -= tap * tci * tco;
+    const int co0 = (local / tci) * 32, ci0 = (local % tci) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int co = co0 + ty + 8 * j, ci = ci0 + tx;
+        tile[ty + 8 * j][tx] = (co < en.Cout && ci < en.Cin) ? en.w[((size_t)co * en.T + tap) * en.Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ci = ci0 + ty + 8 * j, co = co0 + tx;
+        if (ci < en.Cin && co < en.Cout) en.wt[((size_t)ci * en.T + tap) * en.Cout + co] = tile[tx][ty + 8 * j];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dvs_conv2d_pack_wt_batch(const void* table, int n_entries, int total_workgroups, void* stream) {
+    DVS_REQUIRE(table && n_entries > 0 && total_workgroups > 0, "dvs_conv2d_pack_wt_batch: bad argument");
+    hipLaunchKernelGGL(pack_wt_batch_kernel, dim3(total_workgroups), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const PackEntry*>(table), n_entries);
+    return dvs::check_launch("dvs_conv2d_pack_wt_batch");
+}
 
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream) {
     DVS_REQUIRE(w && wt && Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "dvs_conv2d_pack_wt: bad argument");

@@ -164,6 +164,10 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(flat.params)
         self.step_count = 0
         self.param_groups = [{"lr": lr, "betas": betas, "eps": eps}]   # scheduler-compatible view
+        # data-gradient weight packs of the arena's convolutions, refreshed in one launch after every step
+        from . import conv as _conv
+        self.packed = _conv.PackedWeights(flat.tensors)
+        self.packed.repack()
 
     def step(self, grad_scale=1.0, zero_grad=True):
         self.step_count += 1
@@ -173,6 +177,13 @@ class FusedAdam:
         check(_lib.lib().dvs_adam_step(ptr(f.params), ptr(f.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
                                        f.numel, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
                                        grad_scale, int(zero_grad), _lib.stream()), "dvs_adam_step")
+        self.packed.repack()
+
+    def __del__(self):
+        try:
+            self.packed.release()
+        except Exception:
+            pass
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

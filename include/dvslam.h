@@ -124,6 +124,11 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *                       nchw_planar; act/stats ignored).  With nchw_planar dw is packed [Cout][Cin][kh][8].
  *   Channel counts must be multiples of 4 (NHWC 16-byte gathers). */
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
+/*   dvs_conv2d_pack_wt_batch: the same transpose for many weights in one launch.  `table` (device memory) = n_entries
+ *   records { const float* w; float* wt; int Cout, Cin, taps, wg_begin; } (32 bytes each), wg_begin = number of
+ *   workgroups of the records before it, a record needs taps * ceil(Cin/32) * ceil(Cout/32) workgroups;
+ *   total_workgroups = their sum.  The weights change once per optimiser step: dp.FusedAdam repacks right after it. */
+int dvs_conv2d_pack_wt_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 /*   dx_skip / C1 (upsample+concat forward only, else NULL / 0): the gradient is split in the epilogue --
  *   channels [0,C1) are summed over each 2x2 block into dx = [B,H/2,W/2,C1] with atomics (caller zero-fills dx),
  *   channels [C1,Cin) are stored to dx_skip = [B,H,W,Cin-C1]; C1 == Cin (upsample only) needs no dx_skip. */
