@@ -26,7 +26,7 @@ def family(n):
         return "conv_dgrad_kernel"
     if "bn_bwd" in n:
         return "bn_bwd_kernel"
-    if "bn_apply_fwd" in n or "bn_finalize" in n:
+    if "bn_apply_fwd" in n or "bn_finalize" in n or "bn_fwd_fused" in n:
         return "bn_fwd_kernel"
     return base.split("<")[0][-48:]
 
