@@ -118,7 +118,9 @@ class MonodepthTrainer:
             # both frame pairs in one PoseNet pass of batch 2B (per-pair BatchNorm statistics inside): half the launches,
             # twice the rows per convolution
             B = tgt.shape[0]
-            pair = torch.cat([torch.cat([left, tgt], dim=1), torch.cat([tgt, right], dim=1)], dim=0)
+            pair = torch.empty((2 * B, left.shape[1] + tgt.shape[1]) + tuple(tgt.shape[2:]), device=tgt.device, dtype=tgt.dtype)
+            torch.cat([left, tgt], dim=1, out=pair[:B])          # written in place: two copies instead of three, half the bytes
+            torch.cat([tgt, right], dim=1, out=pair[B:])
             axisangle, translation = self.pose_net(pair, pairs=2)
             axisangle_left, axisangle_right = axisangle[:B], axisangle[B:]
             translation_left, translation_right = translation[:B], translation[B:]
