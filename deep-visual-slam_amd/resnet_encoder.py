@@ -111,8 +111,12 @@ class ResnetEncoder(nn.Module):
         self.features = []
         # (x - 0.45) / 0.225 is folded into conv1's gather of the planar image (resnet_encoder.py:102-103)
         nch = input_image.shape[1]
-        scale = torch.full((nch,), 1.0 / 0.225, device=input_image.device)
-        shift = torch.full((nch,), -0.45 / 0.225, device=input_image.device)
+        key = (input_image.device, nch)
+        if getattr(self, "_norm_key", None) != key:     # constants: built once, not two fill launches per forward
+            self._norm_key = key
+            self._norm = (torch.full((nch,), 1.0 / 0.225, device=input_image.device),
+                          torch.full((nch,), -0.45 / 0.225, device=input_image.device))
+        scale, shift = self._norm
         self.features.append(nn_ops.conv_bn_act(input_image, e.conv1.weight, e.bn1, 2, 3, relu=True,
                                                 planar_norm=(scale, shift)))
         x = nn_ops.max_pool_3x3_s2(self.features[-1])
