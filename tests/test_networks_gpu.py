@@ -181,3 +181,33 @@ def test_posenet_pairs_in_one_pass_equal_two_calls(gpu_device):
             assert int(ba) == int(bb) == 2, n
         elif ".fc." not in n:
             assert rel(bb, ba) < 1e-5, n
+
+
+@pytest.mark.parametrize("name", ["layers_level_skip", "layers_level_noskip"])
+def test_decoder_level_matches_reference_goldens(gpu_device, name):
+    """One decoder level through the drop-in modules (fused upsample + concat gather, ELU / sigmoid epilogues, heads on
+    the vector ALUs) against vectors produced by the reference's own model/layers.py (tests/golden/make_golden_layers.py)."""
+    import os
+    from deep_visual_slam_amd.layers import Conv3x3, ConvBlock
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    T = lambda k: torch.from_numpy(g[k]).to(gpu_device)
+    c_mid, c_in = g["blk0.conv.conv.weight"].shape[:2]
+    c_out, c_cat = g["blk1.conv.conv.weight"].shape[:2]
+    blk0, blk1, head = ConvBlock(c_in, c_mid), ConvBlock(c_cat, c_out), Conv3x3(c_out, 1)
+    for mod, pre in ((blk0, "blk0."), (blk1, "blk1."), (head, "head.")):
+        mod.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)})
+        mod.to(gpu_device).to(memory_format=torch.channels_last)
+    x = T("x").requires_grad_(True)
+    skip = T("skip").requires_grad_(True) if "skip" in g.files else None
+    feat = blk1(blk0(x), skip=skip, upsample=True)
+    disp = head(feat, act="sigmoid")
+    assert rel(feat, T("feat")) < 2e-5 and rel(disp, T("disp")) < 2e-5
+    ins = [x] + ([skip] if skip is not None else [])
+    params = [("blk0.", blk0), ("blk1.", blk1), ("head.", head)]
+    plist = [(pre + k, p) for pre, m in params for k, p in m.named_parameters()]
+    grads = torch.autograd.grad([feat, disp], ins + [p for _, p in plist], [T("cot_feat"), T("cot_disp")])
+    assert rel(grads[0], T("d_x")) < 1e-4
+    if skip is not None:
+        assert rel(grads[1], T("d_skip")) < 1e-4
+    for (k, _), gr in zip(plist, grads[len(ins):]):
+        assert rel(gr, T("d_" + k)) < 1e-4, k

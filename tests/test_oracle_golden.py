@@ -143,3 +143,26 @@ def test_fp64_oracle_brackets_fp32():
     sample, disps, poses, noise, ns = golden_chain_inputs(rec)
     _, losses, grads = O.loss_chain_with_grads(sample, disps, poses, noise, dtype=torch.float64)
     assert abs(float(losses["loss"]) - float(rec["loss"])) < 2e-6 * abs(float(rec["loss"])) + 1e-7
+
+
+@pytest.mark.parametrize("name", ["layers_level_skip", "layers_level_noskip"])
+def test_decoder_level_matches_reference_layers(name):
+    """oracle/networks.py's decoder level against vectors produced by the reference's own model/layers.py modules
+    (tests/golden/make_golden_layers.py): values and every input / weight gradient."""
+    import os
+    from oracle import networks as ON
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    sd = {k: T(k).requires_grad_(True) for k in g.files if k.startswith(("blk0.", "blk1.", "head."))}
+    x = T("x").requires_grad_(True)
+    skip = T("skip").requires_grad_(True) if "skip" in g.files else None
+    feat, disp = ON.decoder_level(x, skip, sd, "blk0.conv.conv", "blk1.conv.conv", "head.conv")
+    assert torch.allclose(feat, T("feat"), atol=1e-6, rtol=1e-5) and torch.allclose(disp, T("disp"), atol=1e-6, rtol=1e-5)
+    ins = [x] + ([skip] if skip is not None else [])
+    keys = sorted(sd)
+    grads = torch.autograd.grad([feat, disp], ins + [sd[k] for k in keys], [T("cot_feat"), T("cot_disp")])
+    assert torch.allclose(grads[0], T("d_x"), atol=1e-5, rtol=1e-4)
+    if skip is not None:
+        assert torch.allclose(grads[1], T("d_skip"), atol=1e-5, rtol=1e-4)
+    for k, gr in zip(keys, grads[len(ins):]):
+        assert torch.allclose(gr, T("d_" + k), atol=1e-4, rtol=1e-4), k
