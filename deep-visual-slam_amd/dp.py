@@ -95,13 +95,40 @@ class GradSync:
         self.buckets = []          # (start, end) element ranges
         self.bucket_of = []
         cap = bucket_bytes // 4
+        n = len(flat.tensors)
+        ends = [flat.offsets[i + 1] if i + 1 < n else flat.numel for i in range(n)]
+        # A bucket is reduced when its LAST gradient exists.  Slots are in backward order per network, and the networks
+        # run their backward passes concurrently on their own streams (hook_streams), so (1) no bucket spans two
+        # networks -- it would wait for both -- and (2) the tail of each network (its stem: the gradients that only exist
+        # at the very end of the step) is a small bucket of its own, so that the all-reduce left exposed after backward
+        # moves ~tail_bytes instead of a full bucket.
+        def stream_of(i):
+            return hook_streams.get(id(flat.tensors[i])) if hook_streams else None
+        seg_last = [i for i in range(n) if i + 1 == n or stream_of(i + 1) is not stream_of(i)]
+        tail = min(cap // 8, (2 << 20) // 4)
+        cuts = set(seg_last)                               # tensor indices after which a bucket ends
+        seg_first = 0
+        for last in seg_last:
+            start_el = flat.offsets[seg_first]
+            acc = start_el
+            for i in range(seg_first, last + 1):
+                if ends[i] - acc >= cap:
+                    cuts.add(i)
+                    acc = ends[i]
+            # split the segment's final tensors (<= tail elements) off the last bucket when that bucket is much larger
+            j = last
+            while j > seg_first and ends[last] - flat.offsets[j - 1] <= tail and (j - 1) not in cuts:
+                j -= 1
+            prev_cut = max([c for c in cuts if c < j] + [seg_first - 1])
+            if j <= last and j - 1 > prev_cut and ends[j - 1] - (flat.offsets[prev_cut + 1]) >= 4 * tail:
+                cuts.add(j - 1)
+            seg_first = last + 1
         start = 0
-        for i, (p, o) in enumerate(zip(flat.tensors, flat.offsets)):
-            end = flat.offsets[i + 1] if i + 1 < len(flat.offsets) else flat.numel
+        for i in range(n):
             self.bucket_of.append(len(self.buckets))
-            if end - start >= cap or i + 1 == len(flat.tensors):
-                self.buckets.append((start, end))
-                start = end
+            if i in cuts:
+                self.buckets.append((start, ends[i]))
+                start = ends[i]
         self.sizes = [0] * len(self.buckets)
         for b in self.bucket_of:
             self.sizes[b] += 1
