@@ -168,9 +168,16 @@ def inference_side(device, with_cpu):
     t = timeit(frame, dn, pn)
     gd, gp = inference.Graphed(dn, tgt), inference.Graphed(pn, pair)
     tg = timeit(frame, gd, gp)
+    fp_e = inference.FramePredictor(dn, pn, tgt, pair, graph=False)
+    fp_g = inference.FramePredictor(dn, pn, tgt, pair, graph=True)
+    t2 = timeit(lambda d, p: fp_e(tgt, pair), None, None)
+    t2g = timeit(lambda d, p: fp_g(tgt, pair), None, None)
     res["predict_frame"] = {"workload": "PoseNet(pair) + pose matrix + DepthNet(frame) + depth, as vo/predict.py:63-86",
                             "eager_frames_per_s": 1.0 / t, "graph_frames_per_s": 1.0 / tg,
-                            "eager_ms": t * 1e3, "graph_ms": tg * 1e3}
+                            "eager_ms": t * 1e3, "graph_ms": tg * 1e3,
+                            "two_stream_eager_ms": t2 * 1e3, "two_stream_graph_ms": t2g * 1e3,
+                            "two_stream_graph_frames_per_s": 1.0 / t2g,
+                            "note": "two_stream_*: inference.FramePredictor (PoseNet and DepthNet side by side)"}
     if with_cpu:
         from oracle import networks as ON
         cores = min(len(os.sched_getaffinity(0)), 16)

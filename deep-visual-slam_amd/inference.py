@@ -6,9 +6,10 @@ front of it and lets the conv epilogue add the identity and apply the ReLU (one 
 This module adds the two optional extras a real-time loop wants:
 
   * `depth_net.inference_scales = (0,)`   skip the three coarse disparity heads nobody reads at inference;
-  * `Graphed(net, example)`               capture `net(example)` into a HIP graph and replay it per frame -- at batch 1
-                                          the ~90 launches of a frame are issue-bound from Python (unlike the training
-                                          step, where eager issue is faster than a graph).
+  * `Graphed(net, example)`               capture `net(example)` into a HIP graph and replay it per frame;
+  * `FramePredictor(depth, pose, ...)`    the whole per-frame work with PoseNet and DepthNet on two streams (and, by
+                                          default, as one graph with a fork / join): at batch 1 neither network fills
+                                          the chip, so running them side by side is worth more than the graph.
 """
 import torch
 
@@ -48,6 +49,56 @@ class Graphed:
         if x.shape != self.static_in.shape:
             raise _lib.DvsError("Graphed: captured for input %s, got %s" % (tuple(self.static_in.shape), tuple(x.shape)))
         self.static_in.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
+class FramePredictor:
+    """The per-frame work of vo/predict.py:63-86 -- PoseNet on the frame pair + 4x4 pose matrix, DepthNet on the target
+    frame + depth -- with the two networks on two HIP streams (they are independent, and at batch 1 neither fills the
+    chip), optionally captured as ONE HIP graph with a fork / join.  Returns (T [B,4,4], depth [B,1,H,W], disp); with
+    graph=True these are the graph's static outputs (consume or clone them before the next call)."""
+
+    def __init__(self, depth_net, pose_net, target, pair, min_depth=0.1, max_depth=10.0, invert=False, graph=True,
+                 warmup=3):
+        if depth_net.training or pose_net.training:
+            raise _lib.DvsError("FramePredictor: put both networks in eval() mode first")
+        from .layers import disp_to_depth, transformation_from_parameters
+        self._d2d, self._t = disp_to_depth, transformation_from_parameters
+        self.depth_net, self.pose_net = depth_net, pose_net
+        self.min_depth, self.max_depth, self.invert = min_depth, max_depth, invert
+        self.side = torch.cuda.Stream(device=target.device)
+        self.graph = None
+        if graph:
+            self.s_target, self.s_pair = target.detach().clone(), pair.detach().clone()
+            warm = torch.cuda.Stream(device=target.device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm), torch.no_grad():
+                for _ in range(warmup):
+                    self._run(self.s_target, self.s_pair)
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_out = self._run(self.s_target, self.s_pair)
+
+    def _run(self, target, pair):
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            aa, t = self.pose_net(pair)
+            T = self._t(aa[:, 0], t[:, 0], invert=self.invert)
+        disp = self.depth_net(target)[("disp", 0)]
+        _, depth = self._d2d(disp, self.min_depth, self.max_depth)
+        main.wait_stream(self.side)
+        return T, depth, disp
+
+    def __call__(self, target, pair):
+        if self.graph is None:
+            with torch.no_grad():
+                return self._run(target, pair)
+        self.s_target.copy_(target, non_blocking=True)
+        self.s_pair.copy_(pair, non_blocking=True)
         self.graph.replay()
         return self.static_out
 

@@ -106,3 +106,27 @@ def test_eval_with_grad_keeps_autograd(gpu_device, eval_nets):
     out.mean().backward()
     assert dn.encoder.encoder.layer1[0].conv1.weight.grad is not None
     dn.zero_grad()
+
+
+def test_frame_predictor_two_streams(gpu_device, eval_nets):
+    """PoseNet and DepthNet side by side (eager and as one graph with a fork / join) equal the sequential calls."""
+    from deep_visual_slam_amd import inference
+    from deep_visual_slam_amd.layers import disp_to_depth, transformation_from_parameters
+    dn, pn, _, _ = eval_nets
+    inference.prepare(dn, pn, scales=(0,))
+    try:
+        torch.manual_seed(8)
+        x = torch.rand(1, 3, 96, 128, device=gpu_device)
+        x6 = torch.rand(1, 6, 96, 128, device=gpu_device)
+        with torch.no_grad():
+            aa, t = pn(x6)
+            T0 = transformation_from_parameters(aa[:, 0], t[:, 0], invert=False).clone()
+            d0 = disp_to_depth(dn(x)[("disp", 0)], 0.1, 10.0)[1].clone()
+        for graph in (False, True):
+            fp = inference.FramePredictor(dn, pn, torch.zeros_like(x), torch.zeros_like(x6), graph=graph)
+            for _ in range(2):
+                T, depth, disp = fp(x, x6)
+                torch.cuda.synchronize()
+                assert rel(T, T0) < 1e-5 and rel(depth, d0) < 1e-5 and disp.shape == (1, 1, 96, 128)
+    finally:
+        dn.inference_scales = None
