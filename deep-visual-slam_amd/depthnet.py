@@ -5,7 +5,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .layers import Conv3x3, ConvBlock, upsample
+from .layers import Conv3x3, ConvBlock
 from .resnet_encoder import ResnetEncoder
 
 

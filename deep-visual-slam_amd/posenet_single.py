@@ -6,7 +6,6 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import nn_ops
 from .resnet_encoder import ResnetEncoder

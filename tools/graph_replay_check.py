@@ -2,10 +2,10 @@
 import sys, torch
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
-from deep_visual_slam_amd import inference, nn_ops
+from deep_visual_slam_amd import inference
 from deep_visual_slam_amd.depthnet import DepthNet
 from deep_visual_slam_amd.posenet_single import PoseNet
-from test_inference_gpu import _randomise_bn, rel
+from test_inference_gpu import rel
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 dn = DepthNet(18, pretrained=False).to(dev).eval()
