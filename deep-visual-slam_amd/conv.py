@@ -9,6 +9,7 @@ out of a kernel.  One call covers what the reference spells as several modules:
     (x - 0.45) / 0.225 -> conv1                                  (model/resnet_encoder.py:102-103)
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -212,6 +213,9 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
     return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
+_PREACT = os.environ.get("DVS_CONV_PREACT", "1") != "0"
+
+
 class _Conv2d(torch.autograd.Function):
     """y = act(conv(pad(x [, upsample+concat x2]), w) + b) with the hand-written forward / data-gradient /
     weight-gradient kernels."""
@@ -244,6 +248,15 @@ class _Conv2d(torch.autograd.Function):
             return None, None, None, None, None
         if ctx.up_only:
             x2 = UPSAMPLE_ONLY
+        if (_PREACT and ACT[act] and reflect and not planar and weight.shape[0] >= 64 and (ctx.needs_input_grad[0] or x2 is not None)
+                and ctx.needs_input_grad[1]):
+            # wide decoder layers (register-staged data / weight gradients): form dZ = dY * act'(Y) once instead of in
+            # both kernels' gathers (the data gradient re-derives it for every tap and N tile)
+            dy = _nhwc(dy)
+            dz = torch.empty_like(dy)
+            check(_lib.lib().dvs_act_bwd(dy.data_ptr(), _nhwc(y).data_ptr(), dz.data_ptr(), dy.numel(), ACT[act], _lib.stream()),
+                  "dvs_act_bwd")
+            dy, y, act = dz, None, None
         need_x = ctx.needs_input_grad[0] or (isinstance(x2, torch.Tensor) and ctx.needs_input_grad[3])
         if need_x:
             if planar:

@@ -577,6 +577,19 @@ __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ 
     }
 }
 
+// dZ = dY * act'(Y): the pre-activation gradient as a tensor, for the layers whose data- and weight-gradient kernels
+// would otherwise both re-derive it in their gathers (9 taps x N tiles times per element in the data gradient)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dz, size_t nvec, int act) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(v[e], act);
+    reinterpret_cast<f32x4*>(dz)[i] = g;
+}
+
 // Every data-gradient weight pack of a network in ONE launch (the weights only change at the optimiser step, so
 // dp.FusedAdam repacks them all right after it instead of 51 small launches inside the backward pass).
 struct PackEntry {
@@ -616,6 +629,14 @@ __global__ __launch_bounds__(256) void pack_wt_batch_kernel(const PackEntry* __r
 }  // namespace
 
 extern "C" {
+
+int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, void* stream) {
+    DVS_REQUIRE(dy && y && dz && n > 0 && (n & 3) == 0 && act >= 0 && act <= 3, "dvs_act_bwd: bad argument");
+    const size_t nvec = n / 4;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y,
+                       dz, nvec, act);
+    return dvs::check_launch("dvs_act_bwd");
+}
 
 int dvs_conv2d_pack_wt_batch(const void* table, int n_entries, int total_workgroups, void* stream) {
     DVS_REQUIRE(table && n_entries > 0 && total_workgroups > 0, "dvs_conv2d_pack_wt_batch: bad argument");

@@ -173,9 +173,11 @@ def test_posenet_pairs_in_one_pass_equal_two_calls(gpu_device):
     assert rel(aab, torch.cat([aa1, aa2])) < 1e-5 and rel(tb, torch.cat([t1, t2])) < 1e-5
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         if pa.grad is not None:
-            # run-to-run jitter of the float atomics reaches ~5e-3 on the stem's BatchNorm at this size (it sits at the
-            # end of a 40-layer backward chain with 24-sample batches); a grouping bug would be an O(1) error
-            assert rel(pb.grad, pa.grad) < 2e-2, n
+            # the two sides sum in different orders (other tiles / split-K partitions for a batch of 2B, float atomics), and
+            # the stem sits at the end of a 40-layer backward chain through BatchNorms with 24-sample batches: the
+            # difference reaches ~2e-2 there (5e-3 run to run).  A grouping bug -- statistics over the whole batch instead
+            # of per pair -- is an O(1) error.
+            assert rel(pb.grad, pa.grad) < 5e-2, n
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         if "num_batches_tracked" in n:
             assert int(ba) == int(bb) == 2, n
