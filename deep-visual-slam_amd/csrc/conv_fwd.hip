@@ -164,9 +164,9 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
         (void)bm_rows;
         stats = (m0 < p.stat_split && m0 + bm > p.stat_split) ? 2 : 1;
     }
-    if (MODE == IN_DGRAD) {
+    if (MODE == IN_DGRAD && p.ksplit <= 1) {
         conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
-    } else if (p.ksplit > 1) {
+    } else if (p.ksplit > 1) {       // (data gradients only split when their rows are plain pixels: stride 1, no upsample split)
         const int ln = lane & 31, lh = lane >> 5;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -458,13 +458,14 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     FwdParams q = p;
     q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
     q.ksplit = 1;
-    if constexpr (MODE != IN_DGRAD) {
+    if (MODE != IN_DGRAD || (p.s.stride == 1 && p.split_c1 == 0)) {
         // Few output pixels (batch-1 inference: 300 ... 4800 rows in layers 2-4 and the coarse decoder levels) leave most
         // of the 256 CUs without a tile while each tile walks a K of thousands: split the channel blocks over several
-        // workgroups.  Training batches never get here (their grids cover the chip and they need the statistics epilogue).
+        // workgroups.  Also taken by small training launches without a statistics epilogue (decoder level 4, batch-4 data
+        // gradients of layer 4).
         static const bool splitk = [] { const char* e = getenv("DVS_CONV_SPLITK"); return !(e && e[0] == '0'); }();
         const int tiles = grid.x * grid.y, nC = p.s.Cin / BK;
-        if (splitk && !p.stats && tiles < 128 && nC >= 2 && (p.s.Cout & 3) == 0) {
+        if (splitk && !p.stats && tiles < 200 && nC >= 2 && (p.s.Cout & 3) == 0) {
             int want = min(nC, (256 + tiles - 1) / tiles);
             const int per = (nC + want - 1) / want;
             q.ksplit = (nC + per - 1) / per;
