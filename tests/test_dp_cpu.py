@@ -125,3 +125,33 @@ def test_post_accumulate_hook_fires_for_none_gradients():
     (F.apply(x, w) + F.apply(2 * x, w)).sum().backward()
     assert fired == [1]
     assert float(w.grad.abs().max()) == 0.0
+
+
+def test_bucket_layout_follows_the_streams():
+    """Buckets tile the arena in order, never span parameters registered under different streams (the two networks run
+    their backward passes concurrently), and each stream segment ends in a small tail bucket (the gradients that only
+    exist at the very end of the step)."""
+    import torch
+    from deep_visual_slam_amd import dp
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(12)])      # 12 x 65 792 parameters
+    b = torch.nn.Sequential(*[torch.nn.Linear(256, 256) for _ in range(7)])
+    flat = dp.FlatParams(dp.trainable_parameters(a, b), grad_sinks=False)
+    marker = object()
+    streams = {id(p): marker for p in b.parameters()}
+    gs = dp.GradSync(flat, bucket_bytes=1 << 20, hook_streams=streams)            # 262 144 floats per bucket
+    assert gs.buckets[0][0] == 0 and gs.buckets[-1][1] == flat.numel
+    assert all(x[1] == y[0] for x, y in zip(gs.buckets, gs.buckets[1:]))
+    owner = [streams.get(id(p)) for p in flat.tensors]
+    for bkt in range(len(gs.buckets)):
+        members = {owner[i] for i, bo in enumerate(gs.bucket_of) if bo == bkt}
+        assert len(members) == 1, "bucket %d spans two streams" % bkt
+    # the last bucket of each segment is the small tail (<= bucket/8 elements, or the segment's last tensor alone when that
+    # is larger), the others reach the requested size
+    seg_last = [i for i in range(len(owner)) if i + 1 == len(owner) or owner[i + 1] is not owner[i]]
+    seg_last_bucket = [gs.bucket_of[i] for i in seg_last]
+    for i, bkt in zip(seg_last, seg_last_bucket):
+        s, e = gs.buckets[bkt]
+        assert e - s <= max((1 << 20) // 4 // 8, flat.tensors[i].numel()) + 256
+    full = [e - s for k, (s, e) in enumerate(gs.buckets) if k not in seg_last_bucket and k + 1 not in seg_last_bucket]
+    assert all(n >= (1 << 20) // 4 for n in full)
