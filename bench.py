@@ -342,7 +342,12 @@ def main():
         if world == 1 and args.config == "c3" and not args.no_other_configs:
             # BASELINE.json configs[1] (batch 4, single-scale loss) beside the headline workload: same code path,
             # same timing discipline, reported for reference -- `value` above is the batch-12 4-scale step
-            del trainer, flat, sync, opt, sample, losses
+            del trainer, flat, sync, opt, sample, losses, pose_stream
+            import gc
+            from deep_visual_slam_amd import gradsink
+            torch.cuda.synchronize()
+            gradsink.reset_streams()             # the first trainer's streams must not linger (hardware queues are few)
+            gc.collect()
             torch.cuda.empty_cache()
             c2 = CONFIGS["c2"]
             tr2, _, sync2, opt2, sample2 = build_gpu(c2["batch"], c2["num_scales"], device, rank)
@@ -358,6 +363,9 @@ def main():
                                                    "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
                                                    "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"]}}
             del tr2, sync2, opt2, sample2
+            torch.cuda.synchronize()
+            gradsink.reset_streams()
+            gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"]["configs[0]"] = inference_side(device, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)

@@ -549,7 +549,12 @@ void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
     }
     if (s.Cout > 64) {
         // few output pixels (layer3/4, pose decoder): halve the M tile so the grid still covers the 256 CUs
-        if (small || ((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
+        // ... and once more (64 x 64 tiles) when even that leaves half the chip without a tile and the launch cannot split K
+        // (statistics epilogue): layers 3 / 4 of a batch-4 step
+        static const bool small_m = [] { const char* e = getenv("DVS_CONV_SMALLM"); return !(e && e[0] == '0'); }();
+        const int t64 = ((M + 63) / 64) * ((s.Cout + 127) / 128);
+        if (small_m && MODE != IN_DGRAD && p.stats && t64 < 160) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
+        else if (small || ((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
         else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, slot);
     } else if (s.Cout > 32) {
         if (small) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
