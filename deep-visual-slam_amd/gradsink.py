@@ -60,6 +60,8 @@ import torch
 
 _side = {}          # (device index, compute stream handle) -> (compute stream, its side stream)
 _enabled = os.environ.get("DVS_WGRAD_STREAM", "1") != "0"
+# DVS_WGRAD_STREAM=shared: both networks' weight gradients on ONE side stream (three streams per process instead of four)
+_shared = os.environ.get("DVS_WGRAD_STREAM", "1") == "shared"
 
 
 def enable_side_streams(on):
@@ -78,7 +80,12 @@ def side_stream():
     key = (cur.device_index, cur.cuda_stream)
     pair = _side.get(key)
     if pair is None:
-        pair = _side[key] = (cur, torch.cuda.Stream(device=cur.device))
+        shared = None
+        if _shared:                          # one side stream per device, whatever the compute stream
+            for (dev, _), (_, side) in _side.items():
+                if dev == cur.device_index:
+                    shared = side
+        pair = _side[key] = (cur, shared if shared is not None else torch.cuda.Stream(device=cur.device))
     return pair[1]
 
 
