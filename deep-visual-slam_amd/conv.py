@@ -248,14 +248,26 @@ class _Conv2d(torch.autograd.Function):
             return None, None, None, None, None
         if ctx.up_only:
             x2 = UPSAMPLE_ONLY
+        pre_db = None        # bias gradient already taken by the pre-activation pass (tensor to hand back, or True if sunk)
         if (_PREACT and ACT[act] and reflect and not planar and weight.shape[0] >= 64 and (ctx.needs_input_grad[0] or x2 is not None)
                 and ctx.needs_input_grad[1]):
-            # wide decoder layers (register-staged data / weight gradients): form dZ = dY * act'(Y) once instead of in
-            # both kernels' gathers (the data gradient re-derives it for every tap and N tile)
+            # wide decoder layers: form dZ = dY * act'(Y) once instead of in both gradient kernels' gathers (the data
+            # gradient re-derives it for every tap and N tile), and take the bias gradient (column sums of dZ) in the same
+            # pass -- the weight gradient then has neither an activation nor a bias path and runs on the LDS-DMA kernel
             dy = _nhwc(dy)
             dz = torch.empty_like(dy)
-            check(_lib.lib().dvs_act_bwd(dy.data_ptr(), _nhwc(y).data_ptr(), dz.data_ptr(), dy.numel(), ACT[act], _lib.stream()),
-                  "dvs_act_bwd")
+            Cout = weight.shape[0]
+            db_ptr = None
+            if ctx.has_bias and ctx.needs_input_grad[2] and 256 % (Cout // 4) == 0:
+                bs = gradsink.target(ctx.bias_ref)
+                if bs is not None:
+                    gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
+                    db_ptr, pre_db = bs.data_ptr(), True
+                else:
+                    pre_db = zeropool.zeros((Cout,), dy.device, pooled=ctx.bias_ref.grad is not None)
+                    db_ptr = pre_db.data_ptr()
+            check(_lib.lib().dvs_act_bwd(dy.data_ptr(), _nhwc(y).data_ptr(), dz.data_ptr(), dy.numel(), ACT[act], db_ptr, Cout,
+                                         _lib.stream()), "dvs_act_bwd")
             dy, y, act = dz, None, None
         need_x = ctx.needs_input_grad[0] or (isinstance(x2, torch.Tensor) and ctx.needs_input_grad[3])
         if need_x:
@@ -274,22 +286,29 @@ class _Conv2d(torch.autograd.Function):
             wsink = None if planar else gradsink.target(weight)
             bsink = None if planar else gradsink.target(ctx.bias_ref)
             # fully sunk (nothing goes back to autograd): run beside the data-gradient chain on the side stream
+            want_b = ctx.has_bias and pre_db is None        # the pre-activation pass may already hold the bias gradient
+            if pre_db is not None:
+                bsink_w = None
+            else:
+                bsink_w = bsink
             side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
             if side is None:
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, torch.cuda.current_stream())
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
-                dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
+                dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                       in_scale=scale, in_shift=shift, nchw_planar=planar,
-                                      pooled=weight.grad is not None, dw_out=wsink, db_out=bsink)
+                                      pooled=weight.grad is not None, dw_out=wsink, db_out=bsink_w)
+                if pre_db is not None and pre_db is not True:
+                    db = pre_db
             else:
                 cur = torch.cuda.current_stream()
                 gradsink.note(weight, cur, side)
                 gradsink.note(ctx.bias_ref, cur, side)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, ctx.has_bias, y, act, x2=x2,
-                                 in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink)
+                    conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
+                                 in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink_w)
                 for t in (x, dy, y, x2):
                     if isinstance(t, torch.Tensor):
                         t.record_stream(side)                # keep the allocator from recycling them under the kernel

@@ -584,16 +584,38 @@ __global__ __launch_bounds__(256) void pack_wt_kernel(const float* __restrict__ 
 }
 
 // dZ = dY * act'(Y): the pre-activation gradient as a tensor, for the layers whose data- and weight-gradient kernels
-// would otherwise both re-derive it in their gathers (9 taps x N tiles times per element in the data gradient)
+// would otherwise both re-derive it in their gathers (9 taps x N tiles times per element in the data gradient).
+// dbias (optional): += column sums of dZ -- the bias gradient, so that the weight-gradient kernel needs no bias path.
+// A thread's 4-channel vector is the same in every grid-stride iteration (C/4 divides 256 when dbias is given).
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      float* __restrict__ dz, size_t nvec, int act) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nvec) return;
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+                                                      float* __restrict__ dz, size_t nvec, int act, float* __restrict__ dbias,
+                                                      int C) {
+    __shared__ f32x4 red[256];
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        if (act == ACT_ELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(v[e], act);
-    reinterpret_cast<f32x4*>(dz)[i] = g;
+            for (int e = 0; e < 4; ++e) g[e] = fmaf(g[e], fminf(v[e], 0.f), g[e]);      // 1 + min(y, 0)
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_out(v[e], act);
+        }
+        reinterpret_cast<f32x4*>(dz)[i] = g;
+        bsum += g;
+    }
+    if (dbias) {
+        const int cv = C / 4;
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < cv) {
+            for (int k = threadIdx.x + cv; k < 256; k += cv) bsum += red[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dbias + threadIdx.x * 4 + e, bsum[e]);
+        }
+    }
 }
 
 // Every data-gradient weight pack of a network in ONE launch (the weights only change at the optimiser step, so
@@ -636,11 +658,15 @@ __global__ __launch_bounds__(256) void pack_wt_batch_kernel(const PackEntry* __r
 
 extern "C" {
 
-int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, void* stream) {
+int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float* dbias, int C, void* stream) {
     DVS_REQUIRE(dy && y && dz && n > 0 && (n & 3) == 0 && act >= 0 && act <= 3, "dvs_act_bwd: bad argument");
+    DVS_REQUIRE(!dbias || (C >= 4 && (C & 3) == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && n % C == 0),
+                "dvs_act_bwd: the bias gradient needs C/4 to divide 256 (C=%d)", C);
     const size_t nvec = n / 4;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y,
-                       dz, nvec, act);
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 512) blocks = 512;                      // grid-stride: few same-address atomics for the bias gradient
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, dz, nvec,
+                       act, dbias, C);
     return dvs::check_launch("dvs_act_bwd");
 }
 

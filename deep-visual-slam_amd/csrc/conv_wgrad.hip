@@ -447,6 +447,148 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
     }
 }
 
+// LDS-DMA weight gradient for the decoder's gathers (reflection padding, nearest-upsample + concat), once the activation
+// derivative has been applied to dY beforehand (dvs_act_bwd) and the bias gradient taken there: same tiles and MFMA loop
+// as above, but a pixel's tap offsets (reflected / upsampled coordinates, one per source tensor) come from a ring of
+// per-(pixel, tap) element offsets -- computed once per pixel by one thread, as in the register-staged kernel -- and the
+// X rows are fetched with flat `global_load_lds_dwordx4` (a lane picks its source tensor by its channel slice; rows
+// past the end of the split fetch the zero page).
+constexpr int PTG = 128;         // pixels per half of the offset ring (8 stages of 16 pixels)
+
+__device__ __forceinline__ void dma16_flat(const float* gp, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(NT) void conv_wgrad_dma_gen_kernel(WgradParams p) {
+    constexpr int BPD = 16;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int D_INS = BM * BPD / 1024, X_INS = BN * BPD / 1024;
+    constexpr int DV = BM / 4, XV = BN / 4;
+    constexpr int D_RPI = 64 / DV, X_RPI = 64 / XV;
+    constexpr int SPR = PTG / BPD;
+    constexpr int NSRC = (MODE == IN_UPCAT) ? 2 : 1, RT = 9;
+    constexpr int NO_TAP = -2147483647 - 1;
+    static_assert(WM * WN == 4 && DV <= 64 && XV <= 64 && D_INS >= 1 && X_INS >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BPD][BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BPD][BN];
+    __shared__ int otab[2 * PTG * RT * NSRC];
+
+    const ConvShape& s = p.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int M = s.B * s.Ho * s.Wo;
+    int lg = xcd_logical(blockIdx.x, p.g.x * p.g.y * p.g.z, p.g.remap);
+    const int bid_x = lg % p.g.x;
+    lg /= p.g.x;
+    const int bid_y = lg % p.g.y, bid_z = lg / p.g.y;
+    const int co0 = bid_x * BM, k0 = bid_y * BN;
+    const int m_begin = bid_z * p.m_per_split, m_end = min(M, m_begin + p.m_per_split);
+
+    // ring fill: thread -> (slot = tid % PTG, taps tid / PTG, + NT / PTG, ...) of one half
+    auto fill_ring = [&](int half, int m_first) {
+        const int slot = tid % PTG, m = m_first + slot;
+        const int mc = min(m, M - 1);
+        const int b = mc / (s.Ho * s.Wo), rem = mc - b * (s.Ho * s.Wo);
+        const int oy = rem / s.Wo, ox = rem - oy * s.Wo;
+        for (int t = tid / PTG; t < RT; t += NT / PTG) {
+            const int tky = t / 3, tkx = t - tky * 3;
+            bool ok = m < m_end;
+            int off = 0, off2 = 0;
+            tap_setup<MODE>(s, p.t, b, oy - s.pad + tky, ox - s.pad + tkx, ok, off, off2);
+            int* e = otab + ((half * PTG + slot) * RT + t) * NSRC;
+            e[0] = ok ? off : NO_TAP;
+            if (NSRC == 2) e[1] = ok ? off2 : NO_TAP;
+        }
+    };
+
+    constexpr int OOB = OOB_OFF;
+    const auto rdy = dma_rsrc(p.dy, (size_t)m_end * s.Cout * 4);
+    const int d_c = (lane % DV) * 4, d_r = lane / DV;
+    int d_off[D_INS];
+#pragma unroll
+    for (int j = 0; j < D_INS; ++j)
+        d_off[j] = (co0 + d_c < s.Cout) ? (((wave * D_INS + j) * D_RPI + d_r) * s.Cout + co0 + d_c) * 4 : OOB;
+    // X rows: my tap, channel slice and source tensor are fixed; the pixel's offsets come from the ring
+    const int x_c = (lane % XV) * 4, x_r = lane / XV;
+    const int k = k0 + x_c;
+    const bool k_ok = k < s.Ktot;
+    const int kc = min(k, s.Ktot - 4), tap = kc / s.Cin, ci = kc - tap * s.Cin;
+    const bool src2 = MODE == IN_UPCAT && ci >= p.t.C1;
+    const float* const x_src = (src2 ? p.t.x2 : p.x) + ci;          // tap_setup's second offset is rebased by -C1
+    const int my_ent = tap * NSRC + (src2 ? 1 : 0);
+
+    auto issue_stage = [&](int mb, int buf) {
+        const int ring = (mb - m_begin) & (2 * PTG - 1);
+        const int d_soff = mb * s.Cout * 4;
+#pragma unroll
+        for (int j = 0; j < D_INS; ++j)
+            dma16_buf(rdy, d_off[j], d_soff, &Ds[buf][(wave * D_INS + j) * D_RPI][0]);
+#pragma unroll
+        for (int j = 0; j < X_INS; ++j) {
+            const int slot = ring + (wave * X_INS + j) * X_RPI + x_r;
+            const int e = otab[slot * RT * NSRC + my_ent];
+            const float* a = (k_ok && e != NO_TAP) ? x_src + e : g_dvs_zero_page_w;
+            dma16_flat(a, &Xs[buf][(wave * X_INS + j) * X_RPI][0]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    const int r = lane & 31, h = lane >> 5;
+    const int a_col = wm * TM * 32 + r, b_col = wn * TN * 32 + r;
+    fill_ring(0, m_begin);
+    fill_ring(1, m_begin + PTG);
+    __syncthreads();
+    if (m_begin < m_end) issue_stage(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0, stage = 0;
+#pragma unroll 1
+    for (int mb = m_begin; mb < m_end; mb += BPD, ++stage) {
+        if ((stage & (SPR - 1)) == 0 && stage > 0) fill_ring(((stage / SPR) + 1) & 1, m_begin + ((stage / SPR) + 1) * PTG);
+        if (mb + BPD < m_end) issue_stage(mb + BPD, buf ^ 1);
+#pragma unroll
+        for (int t = 0; t < BPD / 2; ++t) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m) a[m] = Ds[buf][2 * t + h][a_col + m * 32];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) b[n] = Xs[buf][2 * t + h][b_col + n * 32];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int kk = k0 + (wn * TN + tn) * 32 + r;
+        if (kk >= s.Ktot) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int c = cb + (i & 3) + 8 * (i >> 2);
+                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(WgradParams p, hipStream_t st) {
     const int M = p.s.B * p.s.Ho * p.s.Wo;
@@ -479,6 +621,15 @@ void launch_cfg(WgradParams p, hipStream_t st) {
                 }
             }
             hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM, WN, IN_NHWC, 32>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+            return;
+        }
+    }
+    if constexpr (!FOLD && MODE != IN_PLANAR && BM >= 64) {
+        static const bool gen = [] { const char* e = getenv("DVS_WGRAD_GEN"); return !(e && e[0] == '0'); }();
+        static const bool dma2 = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
+        if (gen && dma2 && (MODE == IN_UPCAT || p.s.pad_mode == PAD_REFLECT) && p.t.dact == 0 && p.dbias == nullptr &&
+            p.s.kh == 3 && p.s.kw == 3 && p.s.stride == 1 && (double)M * p.s.Cout < 536870912.0) {
+            hipLaunchKernelGGL((conv_wgrad_dma_gen_kernel<BM, BN, WM, WN, MODE>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
             return;
         }
     }

@@ -131,8 +131,9 @@ int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int
 int dvs_conv2d_pack_wt_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 /*   dvs_act_bwd: dz = dy * act'(y) over n floats (n % 4 == 0), act as in dvs_conv_fusion -- the pre-activation gradient
  *   as a tensor; dvs_conv2d_dgrad / _wgrad are then called with dact = 0 (nn.ELU / ReLU / Sigmoid backward of
- *   model/layers.py:106-118 done once instead of in both gathers). */
-int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, void* stream);
+ *   model/layers.py:106-118 done once instead of in both gathers).  dbias (NULL = skip): [C] += column sums of dz, the
+ *   bias gradient of the [.., C] tensor (C/4 must divide 256), so that dvs_conv2d_wgrad can be called without dbias. */
+int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float* dbias, int C, void* stream);
 /*   dx_skip / C1 (upsample+concat forward only, else NULL / 0): the gradient is split in the epilogue --
  *   channels [0,C1) are summed over each 2x2 block into dx = [B,H/2,W/2,C1] with atomics (caller zero-fills dx),
  *   channels [C1,Cin) are stored to dx_skip = [B,H,W,Cin-C1]; C1 == Cin (upsample only) needs no dx_skip. */
