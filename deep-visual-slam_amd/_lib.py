@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dvs_conv2d_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp]),
     "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv2d_pack_wt_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "dvs_reflect_fold": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_act_bwd": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int, _vp]),
     "dvs_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp, C.c_int, _vp]),

@@ -111,6 +111,26 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
 _prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape)
 
 
+def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0):
+    """Data gradient of ReflectionPad2d(1) + 3x3 stride-1 conv when dz is already the PRE-activation gradient: the
+    gradient w.r.t. the padded input is a plain zero-padded correlation (the LDS-DMA kernel; no fold, no activation
+    derivative in its gather), dvs_reflect_fold then folds the border back and splits / 2x2-sums for an upsample(+concat)
+    input.  Returns dx, or (d coarse, d skip) as conv2d_dgrad does."""
+    l = _lib.lib()
+    B, Cin, H, W = x_shape
+    g = conv2d_dgrad(dz, weight, (B, Cin, H + 2, W + 2), 1, 0, False, prepadded=True)    # [B, Cin, H+2, W+2] (NHWC memory)
+    if split_c1:
+        dx = torch.empty((B, H // 2, W // 2, split_c1), device=dz.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        dskip = (torch.empty((B, Cin - split_c1, H, W), device=dz.device, dtype=torch.float32, memory_format=CL)
+                 if split_c1 < Cin else None)
+        check(l.dvs_reflect_fold(g.data_ptr(), dx.data_ptr(), dskip.data_ptr() if dskip is not None else None, B, H, W, Cin,
+                                 split_c1, _lib.stream()), "dvs_reflect_fold")
+        return dx, dskip
+    dx = torch.empty((B, Cin, H, W), device=dz.device, dtype=torch.float32, memory_format=CL)
+    check(l.dvs_reflect_fold(g.data_ptr(), dx.data_ptr(), None, B, H, W, Cin, 0, _lib.stream()), "dvs_reflect_fold")
+    return dx
+
+
 class PackedWeights:
     """Data-gradient weight packs ([Cin][kh][kw][Cout]) of a fixed set of convolution weights, refreshed with ONE launch.
     The weights change once per optimiser step, so dp.FusedAdam owns one of these for its arena and calls repack()
@@ -155,7 +175,7 @@ def _packed_weight(w, weight):
     return wt
 
 
-def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0):
+def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False):
     """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
     split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
     (d coarse [B,C1,H/2,W/2] -- the 2x2-summed gradient of the upsampled operand, d skip [B,Cin-C1,H,W] or None)."""
@@ -166,6 +186,8 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
     B, _, H, W = x_shape
     wt = _packed_weight(w, weight)
     d = _desc(B, Cin, H, W, weight.shape, stride, pad, reflect)
+    if prepadded:
+        d.pad_mode = 2           # x_shape is the reflection-padded input: zero padding, unpadded flops in the profile
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
     if split_c1:
@@ -214,6 +236,7 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
 
 
 _PREACT = os.environ.get("DVS_CONV_PREACT", "1") != "0"
+_PADDED = os.environ.get("DVS_CONV_PADDED_DGRAD", "1") != "0"
 
 
 class _Conv2d(torch.autograd.Function):
@@ -248,6 +271,7 @@ class _Conv2d(torch.autograd.Function):
             return None, None, None, None, None
         if ctx.up_only:
             x2 = UPSAMPLE_ONLY
+        preact = False
         pre_db = None        # bias gradient already taken by the pre-activation pass (tensor to hand back, or True if sunk)
         if (_PREACT and ACT[act] and reflect and not planar and weight.shape[0] >= 64 and (ctx.needs_input_grad[0] or x2 is not None)
                 and ctx.needs_input_grad[1]):
@@ -269,18 +293,27 @@ class _Conv2d(torch.autograd.Function):
             check(_lib.lib().dvs_act_bwd(dy.data_ptr(), _nhwc(y).data_ptr(), dz.data_ptr(), dy.numel(), ACT[act], db_ptr, Cout,
                                          _lib.stream()), "dvs_act_bwd")
             dy, y, act = dz, None, None
+            preact = True
         need_x = ctx.needs_input_grad[0] or (isinstance(x2, torch.Tensor) and ctx.needs_input_grad[3])
         if need_x:
             if planar:
                 raise _lib.DvsError("the planar image input of conv1 has no gradient path")
             B = ctx.x_shape[0]
+            padded = (_PADDED and preact and reflect and stride == 1 and pad == 1 and weight.shape[2] == 3
+                      and weight.shape[0] % 32 == 0 and ctx.x_shape[2] >= 2)
             if x2 is None:
-                dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
+                if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:
+                    dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape)
+                else:
+                    dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
             else:
                 C1, H, W = ctx.x_shape[1], 2 * ctx.x_shape[2], 2 * ctx.x_shape[3]
                 # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split: both done in
-                # the data-gradient kernel's epilogue
-                dx, dx2 = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act, split_c1=C1)
+                # the data-gradient kernel's epilogue (or, on the padded-domain path, in dvs_reflect_fold)
+                if padded:
+                    dx, dx2 = conv2d_dgrad_padded(dy, weight, (B, weight.shape[1], H, W), split_c1=C1)
+                else:
+                    dx, dx2 = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act, split_c1=C1)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             # pool-backed scratch only when autograd will add it into an existing .grad (never adopt it)
             wsink = None if planar else gradsink.target(weight)

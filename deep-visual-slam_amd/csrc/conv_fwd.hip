@@ -32,6 +32,8 @@ struct FwdParams {
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
     const float* zero_page;   // 16 bytes of zeros: what the LDS-DMA kernel fetches for padding / tail lanes
     const float* res;         // [B,Ho,Wo,Cout] added before the activation (inference BasicBlock tail), or NULL
+    int work_m;               // rows to count as algorithmic work in the profile (0 = all M rows): the padded-domain data
+                              // gradient computes a border of rows that the unpadded problem does not have
     int ksplit;               // > 1: split-K launch of the LDS-DMA kernel -- raw partial sums are added into a zero-filled y
                               // with atomics, splitk_finish_kernel applies bias / residual / activation afterwards
     Grid3 g;             // logical grid: M tiles, N tiles, parity classes (launched 1-D, see xcd_logical)
@@ -454,7 +456,7 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
     }
     dvs::ProfScope prof(slot, st);
     const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;
-    prof.work(2.0 * M * p.s.Cout * (double)p.s.Ktot * eff);
+    prof.work(2.0 * (p.work_m ? p.work_m : M) * p.s.Cout * (double)p.s.Ktot * eff);
     FwdParams q = p;
     q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
     q.ksplit = 1;
@@ -523,7 +525,7 @@ void launch_buf(const FwdParams& p, hipStream_t st, int slot) {
     // algorithmic flops of the convolution (IN_PLANAR: the 7 real taps of a row, not the 8 padded ones)
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     const double eff = (MODE == IN_DGRAD) ? 1.0 / (p.s.stride * p.s.stride) : 1.0;   // strided taps are empty
-    prof.work(2.0 * M * p.s.Cout * k_real * eff);
+    prof.work(2.0 * (p.work_m ? p.work_m : M) * p.s.Cout * k_real * eff);
     FwdParams q = p;
     q.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_remap_enabled()};
     hipLaunchKernelGGL(kern, dim3(grid.x * grid.y * grid.z), dim3(NT), lds, st, q);
@@ -618,6 +620,61 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Reflection fold + upsample / concat split of a data gradient computed on the PADDED input domain.
+// G [B][H+2][W+2][C] = gradient w.r.t. ReflectionPad2d(1)(input) (a plain zero-padded "full" correlation, which the
+// LDS-DMA kernel runs at full speed).  The mirrored border folds back: padded row 0 -> row 1, row H+1 -> row H-2, same
+// for columns.  One thread per (output pixel or 2x2 block, 4-channel vector):
+//   C1 == 0: dx [B][H][W][C] = fold(G);
+//   C1 > 0 : channels < C1 are summed over each 2x2 block into dx [B][H/2][W/2][C1] (gradient of the nearest upsample),
+//            channels >= C1 go to dx_skip [B][H][W][C-C1].
+__device__ __forceinline__ f32x4 folded_at(const float* __restrict__ G, int b, int y, int x, int c, int H, int W, int C) {
+    const int Wp = W + 2;
+    const float* base = G + ((size_t)b * (H + 2)) * Wp * C + c;
+    auto at = [&](int py, int px) { return *reinterpret_cast<const f32x4*>(base + ((size_t)py * Wp + px) * C); };
+    const int ey = (y == 1) ? 0 : ((y == H - 2) ? H + 1 : -1), ex = (x == 1) ? 0 : ((x == W - 2) ? W + 1 : -1);
+    f32x4 v = at(y + 1, x + 1);
+    if (ey >= 0) v += at(ey, x + 1);
+    if (ex >= 0) v += at(y + 1, ex);
+    if (ey >= 0 && ex >= 0) v += at(ey, ex);
+    if (H == 3 && y == 1) v += at(H + 1, x + 1) + ((ex >= 0) ? at(H + 1, ex) : f32x4{0.f, 0.f, 0.f, 0.f});   // row 1 == row H-2
+    if (W == 3 && x == 1) v += at(y + 1, W + 1) + ((ey >= 0) ? at(ey, W + 1) : f32x4{0.f, 0.f, 0.f, 0.f});
+    if (H == 3 && W == 3 && y == 1 && x == 1) v += at(H + 1, W + 1);
+    return v;
+}
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ G, float* __restrict__ dx,
+                                                           float* __restrict__ dx_skip, int B, int H, int W, int C, int C1) {
+    const int cv = C / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (C1 == 0) {
+        if (i >= (size_t)B * H * W * cv) return;
+        const int c = (int)(i % cv) * 4;
+        size_t m = i / cv;
+        const int x = (int)(m % W);
+        m /= W;
+        const int y = (int)(m % H), b = (int)(m / H);
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + y) * W + x) * C + c) = folded_at(G, b, y, x, c, H, W, C);
+        return;
+    }
+    const int H2 = H >> 1, W2 = W >> 1;
+    if (i >= (size_t)B * H2 * W2 * cv) return;
+    const int c = (int)(i % cv) * 4;
+    size_t m = i / cv;
+    const int x2 = (int)(m % W2);
+    m /= W2;
+    const int y2 = (int)(m % H2), b = (int)(m / H2);
+    f32x4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = folded_at(G, b, 2 * y2 + (q >> 1), 2 * x2 + (q & 1), c, H, W, C);
+    if (c < C1) {
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H2 + y2) * W2 + x2) * C1 + c) = (v[0] + v[1]) + (v[2] + v[3]);
+    } else {
+        const int cs = C - C1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(dx_skip + (((size_t)b * H + 2 * y2 + (q >> 1)) * W + 2 * x2 + (q & 1)) * cs + (c - C1)) = v[q];
+    }
+}
+
 // Every data-gradient weight pack of a network in ONE launch (the weights only change at the optimiser step, so
 // dp.FusedAdam repacks them all right after it instead of 51 small launches inside the backward pass).
 struct PackEntry {
@@ -658,6 +715,16 @@ __global__ __launch_bounds__(256) void pack_wt_batch_kernel(const PackEntry* __r
 
 extern "C" {
 
+int dvs_reflect_fold(const float* g_padded, float* dx, float* dx_skip, int B, int H, int W, int C, int C1, void* stream) {
+    DVS_REQUIRE(g_padded && dx && B > 0 && H >= 3 && W >= 3 && C > 0 && (C & 3) == 0, "dvs_reflect_fold: bad argument");
+    DVS_REQUIRE(C1 == 0 || ((C1 & 3) == 0 && C1 <= C && !((H | W) & 1) && (C1 == C || dx_skip)), "dvs_reflect_fold: bad split");
+    const size_t n = (C1 == 0 ? (size_t)B * H * W : (size_t)B * (H / 2) * (W / 2)) * (C / 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_CONV_DGRAD, st);       // part of the data gradient's time (no flops of its own)
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g_padded, dx, dx_skip, B, H, W, C, C1);
+    return dvs::check_launch("dvs_reflect_fold");
+}
+
 int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float* dbias, int C, void* stream) {
     DVS_REQUIRE(dy && y && dz && n > 0 && (n & 3) == 0 && act >= 0 && act <= 3, "dvs_act_bwd: bad argument");
     DVS_REQUIRE(!dbias || (C >= 4 && (C & 3) == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && n % C == 0),
@@ -665,8 +732,9 @@ int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, f
     const size_t nvec = n / 4;
     size_t blocks = (nvec + 255) / 256;
     if (blocks > 512) blocks = 512;                      // grid-stride: few same-address atomics for the bias gradient
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y, dz, nvec,
-                       act, dbias, C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_CONV_DGRAD, st);       // counted with the data gradient (it serves both gradients)
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, dz, nvec, act, dbias, C);
     return dvs::check_launch("dvs_act_bwd");
 }
 
@@ -692,8 +760,9 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
                 "dvs_conv2d_dgrad: bad upsample+concat split");
     DVS_REQUIRE(d->stride == 1 || d->stride == 2, "dvs_conv2d_dgrad: stride %d (1 or 2 supported)", d->stride);
     DVS_REQUIRE((d->Cout & 3) == 0 && (d->Cin & 3) == 0, "dvs_conv2d_dgrad: channel counts must be multiples of 4");
-    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 2 && d->W >= 2),
-                "dvs_conv2d_dgrad: reflect mode is ReflectionPad2d(1) + 3x3 stride 1 only");
+    DVS_REQUIRE(d->pad_mode == PAD_ZERO || (d->pad_mode == 2 && d->pad == 0 && d->stride == 1 && d->H > 2 && d->W > 2 && !dact && !C1) ||
+                    (d->pad_mode == PAD_REFLECT && d->pad == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->H >= 2 && d->W >= 2),
+                "dvs_conv2d_dgrad: reflect mode is ReflectionPad2d(1) + 3x3 stride 1 only; pad_mode 2 = pre-padded input, pad 0");
     DVS_REQUIRE(!dact || y_out, "dvs_conv2d_dgrad: activation gradient needs the forward output");
     DVS_REQUIRE((double)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) < 2147483648.0,
                 "dvs_conv2d_dgrad: tensors must have fewer than 2^31 elements (32-bit gather offsets)");
@@ -706,6 +775,10 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     s.Ho = d->H; s.Wo = d->W; s.Cout = d->Cin;        // GEMM rows = input pixels, N = input channels
     s.H = Ho; s.W = Wo; s.Cin = d->Cout;              // gathered tensor = dY
     s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
+    if (d->pad_mode == 2) {      // input = an already reflection-padded tensor (dvs_reflect_fold follows): zero padding here,
+        s.pad_mode = PAD_ZERO;   // and the profile counts the unpadded problem's flops
+        p.work_m = d->B * (d->H - 2) * (d->W - 2);
+    }
     s.Ktot = d->kh * d->kw * d->Cout;
     p.t.aux = y_out;
     p.t.dact = dact;

@@ -84,7 +84,8 @@ typedef struct {
     int B, H, W, Cin, Cout;
     int kh, kw, stride;
     int pad;        /* implicit padding on every side */
-    int pad_mode;   /* 0 = zeros (nn.Conv2d padding), 1 = nn.ReflectionPad2d(pad) in front of the conv */
+    int pad_mode;   /* 0 = zeros (nn.Conv2d padding), 1 = nn.ReflectionPad2d(pad) in front of the conv;
+                       dvs_conv2d_dgrad only: 2 = H x W is an already reflection-padded input, pad = 0 (dvs_reflect_fold follows) */
 } dvs_conv_desc;
 
 typedef struct {
@@ -134,6 +135,13 @@ int dvs_conv2d_pack_wt_batch(const void* table, int n_entries, int total_workgro
  *   model/layers.py:106-118 done once instead of in both gathers).  dbias (NULL = skip): [C] += column sums of dz, the
  *   bias gradient of the [.., C] tensor (C/4 must divide 256), so that dvs_conv2d_wgrad can be called without dbias. */
 int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, float* dbias, int C, void* stream);
+/*   dvs_reflect_fold: second half of a reflection-padded conv's data gradient computed on the PADDED domain.  g_padded
+ *   [B][H+2][W+2][C] is the gradient w.r.t. ReflectionPad2d(1)(input) -- dvs_conv2d_dgrad of the equivalent unpadded
+ *   ("valid") conv on an (H+2) x (W+2) input, zero padding, which the LDS-DMA kernel serves; this folds the mirrored
+ *   border back (padded row 0 -> row 1, row H+1 -> row H-2, same for columns) and, for an upsample(+concat) input
+ *   (C1 > 0), sums channels < C1 over 2x2 blocks into dx [B][H/2][W/2][C1] and stores channels >= C1 to dx_skip
+ *   [B][H][W][C-C1]; C1 == 0: dx [B][H][W][C].  (model/layers.py:121-136 backward, model/depthnet.py:79-85.) */
+int dvs_reflect_fold(const float* g_padded, float* dx, float* dx_skip, int B, int H, int W, int C, int C1, void* stream);
 /*   dx_skip / C1 (upsample+concat forward only, else NULL / 0): the gradient is split in the epilogue --
  *   channels [0,C1) are summed over each 2x2 block into dx = [B,H/2,W/2,C1] with atomics (caller zero-fills dx),
  *   channels [C1,Cin) are stored to dx_skip = [B,H,W,Cin-C1]; C1 == Cin (upsample only) needs no dx_skip. */

@@ -36,6 +36,9 @@ CASES = [
     ("thin32_c64", 2, 64, 32, 3, 1, 1, True, 13, 64, "elu", True),
     ("thin16_c32", 2, 32, 16, 3, 1, 1, True, 21, 128, "elu", True),
     ("thin16_c16_nobias", 1, 16, 16, 3, 1, 1, True, 9, 256, None, False),
+    # wide decoder layers: pre-activation pass + padded-domain data gradient + reflection fold + LDS-DMA weight gradient
+    ("refl_elu_wide", 2, 128, 64, 3, 1, 1, True, 12, 20, "elu", True),
+    ("refl_elu_wide_h3", 1, 64, 64, 3, 1, 1, True, 3, 5, "elu", True),
 ]
 
 

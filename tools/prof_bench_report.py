@@ -22,7 +22,7 @@ def family(n):
         return "conv_wgrad_kernel"
     if "thin_fwd" in n:
         return "conv_fwd_kernel"
-    if "thin_dgrad" in n:
+    if "thin_dgrad" in n or "reflect_fold" in n or "act_bwd" in n:
         return "conv_dgrad_kernel"
     if "bn_bwd" in n:
         return "bn_bwd_kernel"
