@@ -38,7 +38,7 @@ class ChainFwdIO(C.Structure):
 
 class ChainBwdIO(C.Structure):
     _fields_ = [("d_losses", _vp), ("d_disp", _vp * MAX_SCALES), ("d_T", _vp * 2),
-                ("bwd_partials", _vp)]
+                ("bwd_partials", _vp), ("scale_begin", C.c_int), ("scale_end", C.c_int), ("phase", C.c_int)]
 
 
 class ConvDesc(C.Structure):

@@ -368,6 +368,7 @@ class _HeadConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        gradsink.wait_pending(dy)                # a disparity gradient may still be on its way on another stream
         x, w, y = ctx.saved_tensors
         pad, reflect, act, has_bias = ctx.cfg
         B, Cin, H, W = x.shape

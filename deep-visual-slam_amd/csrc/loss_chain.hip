@@ -539,8 +539,10 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
     const bool field_thread = tid < FIELD_THREADS;
     const int fpx = X0 - 1 + fcol;
 
+    const int s_lo = (q.g.scale_end > q.g.scale_begin) ? q.g.scale_begin : 0;
+    const int s_hi = (q.g.scale_end > q.g.scale_begin) ? min(q.g.scale_end, S) : S;
 #pragma unroll 1
-    for (int s = 0; s < S; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const int hs = c.hs[s], ws = c.ws[s];
         const bool same_res = (hs == H && ws == W);
         const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
@@ -846,7 +848,10 @@ int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dv
     DVS_REQUIRE(io->sel && io->stats, "dvs_chain_bwd: null forward state");
     DVS_REQUIRE(g->d_losses && g->d_T[0] && g->d_T[1] && g->bwd_partials, "dvs_chain_bwd: null gradient buffer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (int s = 0; s < cfg->num_scales; ++s) {
+    DVS_REQUIRE(g->phase >= 0 && g->phase <= 2 && g->scale_begin >= 0 && g->scale_end <= cfg->num_scales, "dvs_chain_bwd: bad phase / scale range");
+    const int s_lo = (g->scale_end > g->scale_begin) ? g->scale_begin : 0;
+    const int s_hi = (g->scale_end > g->scale_begin) ? g->scale_end : cfg->num_scales;
+    for (int s = (g->phase == 2 ? cfg->num_scales : s_lo); s < s_hi; ++s) {
         DVS_REQUIRE(io->disp[s] && g->d_disp[s], "dvs_chain_bwd: null disp/d_disp[%d]", s);
         if (!(cfg->hs[s] == cfg->H && cfg->ws[s] == cfg->W)) {
             hipError_t e = hipMemsetAsync(g->d_disp[s], 0, (size_t)cfg->B * cfg->hs[s] * cfg->ws[s] * sizeof(float), st);
@@ -856,11 +861,11 @@ int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dv
     ChainParams p = make_params(cfg, io);
     BwdParams q;
     q.g = *g;
-    {
+    if (g->phase != 2) {
         dvs::ProfScope prof(dvs::SLOT_CHAIN_BWD, st);
         hipLaunchKernelGGL(chain_bwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p, q);
     }
-    hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3(cfg->B, 2), dim3(NT), 0, st, p, q);
+    if (g->phase != 1) hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3(cfg->B, 2), dim3(NT), 0, st, p, q);
     return dvs::check_launch("dvs_chain_bwd");
 }
 

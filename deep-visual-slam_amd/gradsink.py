@@ -89,6 +89,26 @@ def side_stream():
     return pair[1]
 
 
+_pending = {}       # data_ptr of a gradient tensor -> event recorded on the stream that produces it
+
+
+def set_pending(tensor, event):
+    """`tensor` (a gradient handed to autograd) is being written on another stream; its consumer calls wait_pending."""
+    _pending[tensor.data_ptr()] = event
+
+
+def wait_pending(tensor):
+    """The current stream waits for the producer of `tensor`, if one was registered (loss-chain backward by scale)."""
+    if _pending and tensor is not None:
+        ev = _pending.pop(tensor.data_ptr(), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+
+def clear_pending():
+    _pending.clear()
+
+
 def reset_streams():
     """Drop the side streams (after join()).  A process that builds a second trainer would otherwise keep the first one's
     compute / side streams alive here, and HIP multiplexes all live streams onto a handful of hardware queues: the new

@@ -71,6 +71,7 @@ class MonodepthTrainer:
         use_stream = tr.get("pose_stream", os.environ.get("DVS_POSE_STREAM", "1") != "0")
         self.pose_stream = (torch.cuda.Stream(device=self.device)
                             if use_stream and torch.device(self.device).type == "cuda" else None)
+        ops.chain_aux_stream = self.pose_stream          # loss-chain backward by scale (DVS_CHAIN_SPLIT=1) runs its coarse scales there
         self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]
 
         # standalone operators kept as public attributes like the reference (learner_new.py:44-57)
@@ -90,6 +91,7 @@ class MonodepthTrainer:
                 sample[key] = sample[key].to(self.device, non_blocking=True)
         gradsink.join()                                          # side-stream kernels of the previous step
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
+        ops.chain_aux_stream = self.pose_stream                  # follows the attribute (bench.py switches it off to time kernels)
         if self.pose_stream is None:
             outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
             outputs.update(self._predict_poses(sample))

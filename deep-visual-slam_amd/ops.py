@@ -1,6 +1,7 @@
 """torch.autograd.Function wrappers over the C-ABI (include/dvslam.h).  PyTorch only provides device
 memory, the stream and the autograd graph here; all arithmetic is in libdvslam_hip.so."""
 import ctypes as C
+import os
 
 import torch
 
@@ -33,6 +34,8 @@ class _PoseToMat(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dM):
+        from . import gradsink
+        gradsink.wait_pending(dM)
         aa, tr = ctx.saved_tensors
         dM = _f32c(dM)
         d_aa, d_tr = torch.empty_like(aa), torch.empty_like(tr)
@@ -63,6 +66,13 @@ def chain_workspace_bytes(cfg):
     sizes = [C.c_size_t() for _ in range(4)]
     check(_lib.lib().dvs_chain_workspace(C.byref(cfg), *[C.byref(s) for s in sizes]), "dvs_chain_workspace")
     return [s.value for s in sizes]
+
+
+# Loss-chain backward by scale on two streams (see _LossChain.backward): used when the trainer has given its second stream
+# (MonodepthTrainer sets chain_aux_stream to the PoseNet stream) AND every gradient it hands out late goes to a consumer that
+# waits for it (gradsink.wait_pending: the disparity heads' and the pose-matrix backward); DVS_CHAIN_SPLIT=0 switches it off.
+_CHAIN_SPLIT = os.environ.get("DVS_CHAIN_SPLIT", "1") != "0"
+chain_aux_stream = None
 
 
 class _LossChain(torch.autograd.Function):
@@ -114,6 +124,7 @@ class _LossChain(torch.autograd.Function):
         ctx.save_for_backward(target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps)
         ctx.opts = dict(opts)
         ctx.nbwd = nb[3]
+        ctx.split_ok = bool(opts.get("split_ok", False))
         ctx.mark_non_differentiable(sel, *extra)
         return (losses, sel, *extra)
 
@@ -144,7 +155,38 @@ class _LossChain(torch.autograd.Function):
         g.d_T[0], g.d_T[1] = ptr(d_T[0]), ptr(d_T[1])
         bwd_partials = torch.empty(ctx.nbwd // 4, device=dev, dtype=torch.float32)
         g.bwd_partials = ptr(bwd_partials)
-        check(_lib.lib().dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), _lib.stream()), "dvs_chain_bwd")
+        aux = chain_aux_stream if (_CHAIN_SPLIT and S > 1 and ctx.split_ok) else None
+        if aux is None:
+            check(_lib.lib().dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), _lib.stream()), "dvs_chain_bwd")
+            return (None, None, None, None, None, None, d_T[0], d_T[1], None, *d_disps)
+        # By scale: the decoder's backward needs d disp_0 first and the coarser scales only later, the PoseNet stream is
+        # idle until d_T exists.  Scale 0 on this stream; scales 1 .. S-1 one after the other on `aux`, then the d_T
+        # reduction there; the consumers (disparity heads, pose-matrix backward) wait for their own event.
+        from . import gradsink
+        l = _lib.lib()
+        main = torch.cuda.current_stream()
+        gradsink.clear_pending()
+        aux.wait_stream(main)                                # d_losses, saved state, the fresh gradient buffers
+        g.scale_begin, g.scale_end, g.phase = 0, 1, 1
+        check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), main.cuda_stream), "dvs_chain_bwd")
+        ev_a = torch.cuda.Event()
+        ev_a.record(main)
+        with torch.cuda.stream(aux):
+            for s in range(1, S):
+                g.scale_begin, g.scale_end, g.phase = s, s + 1, 1
+                check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), aux.cuda_stream), "dvs_chain_bwd")
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                gradsink.set_pending(d_disps[s], ev)
+            aux.wait_event(ev_a)                             # scale 0's partial sums
+            g.scale_begin, g.scale_end, g.phase = 0, 0, 2
+            check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), aux.cuda_stream), "dvs_chain_bwd")
+            ev_t = torch.cuda.Event()
+            ev_t.record(aux)
+        for t in d_T:
+            gradsink.set_pending(t, ev_t)
+        for t in d_disps[1:] + d_T + [bwd_partials, d_losses, sel, stats] + list(disps):
+            t.record_stream(aux)
         return (None, None, None, None, None, None, d_T[0], d_T[1], None, *d_disps)
 
 
@@ -154,6 +196,12 @@ def loss_chain(target, src_l, src_r, K, inv_K, T_l, T_r, disps, noise=None, seed
     per-scale list of dicts {disp_up, depth, grid:(l,r), color:(l,r)} when materialize=True, else []."""
     opts = dict(auto_mask=auto_mask, min_depth=min_depth, max_depth=max_depth, ssim_ratio=ssim_ratio,
                 smoothness_ratio=smoothness_ratio, seed=seed, materialize=materialize)
+    # the backward may hand d disp_1.. and d T out before they are complete (computed on a second stream) only if their
+    # consumers are the nodes that wait for them: the disparity heads and the pose-matrix Function
+    def fn_name(t):
+        return type(t.grad_fn).__name__ if isinstance(t, torch.Tensor) and t.grad_fn is not None else None
+    opts["split_ok"] = (all(fn_name(d) == "_HeadConvBackward" for d in disps[1:])
+                        and all(fn_name(t) in ("_PoseToMatBackward", None) for t in (T_l, T_r)))
     out = _LossChain.apply(opts, target, src_l, src_r, K, inv_K, T_l, T_r, noise, *disps)
     losses, sel, flat = out[0], out[1], out[2:]
     extras = []

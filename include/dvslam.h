@@ -273,6 +273,10 @@ typedef struct {
     float* d_disp[DVS_MAX_SCALES];   /* [B,1,hs,ws]; overwritten (zero-filled inside where needed) */
     float* d_T[2];                   /* [B,4,4] gradient wrt cam_T_cam(-1/+1) */
     float* bwd_partials;             /* workspace */
+    int scale_begin, scale_end;      /* scales [begin, end) handled by this call; 0, 0 = all of them */
+    int phase;                       /* 0: gradient kernel + d_T reduction; 1: gradient kernel only; 2: d_T reduction only
+                                        (after calls with phase 1 have covered every scale) -- lets a caller launch the
+                                        scales on different streams and hand d disp_0 to the decoder's backward first */
 } dvs_chain_bwd_io;
 
 /* Bytes of each workspace buffer for a configuration (host out-params). */

@@ -152,3 +152,49 @@ def test_philox_noise_statistics(gpu_device):
     assert torch.equal(l1, l2) and torch.equal(s1, s2)
     assert not torch.equal(s1, s3)
     assert float((l1 - l0).abs().max()) < 5e-5
+
+
+def test_backward_by_scale_on_two_streams_equals_one_launch(gpu_device):
+    """The loss-chain backward launched by scale (scale 0 on the current stream, the coarser scales and the pose
+    reduction on a second stream, consumers waiting for their events) gives the gradients of the single launch."""
+    from deep_visual_slam_amd import conv as DC, ops, synth
+    B, H, W = 2, 96, 128
+    sample = synth.parity_sample(B, H, W)
+    tgt, left, right = [sample[k].to(gpu_device) for k in (("target_image", 0), ("source_left", 0), ("source_right", 0))]
+    K, inv_K = sample[("K", 0)].to(gpu_device), sample[("inv_K", 0)].to(gpu_device)
+    torch.manual_seed(3)
+    feats = [torch.randn(B, 16, H >> s, W >> s, device=gpu_device).contiguous(memory_format=torch.channels_last) * 0.3
+             for s in range(4)]
+    ws = [(torch.randn(1, 16, 3, 3, device=gpu_device) * 0.2).contiguous(memory_format=torch.channels_last) for _ in range(4)]
+    bs = [torch.zeros(1, device=gpu_device) for _ in range(4)]
+    aa = torch.randn(2, B, 3, device=gpu_device) * 0.01
+    tt = torch.randn(2, B, 3, device=gpu_device) * 0.02
+    noise = torch.randn(4, B, 2, H, W, device=gpu_device)
+
+    def run(split):
+        old = (ops._CHAIN_SPLIT, ops.chain_aux_stream)
+        ops._CHAIN_SPLIT, ops.chain_aux_stream = split, (torch.cuda.Stream(device=gpu_device) if split else None)
+        try:
+            f = [t.clone().requires_grad_(True) for t in feats]
+            a, t = aa.clone().requires_grad_(True), tt.clone().requires_grad_(True)
+            disps = [DC.head_conv2d(f[s], ws[s], bs[s], 0, 1, "sigmoid") for s in range(4)]
+            T_l, T_r = ops.pose_to_mat(a[0], t[0], True), ops.pose_to_mat(a[1], t[1], False)
+            losses, _, _ = ops.loss_chain(tgt, left, right, K, inv_K, T_l, T_r, disps, noise=noise)
+            assert ops._LossChain is not None
+            (losses * torch.tensor([1.0, 0.5, 0.25, 0.125], device=gpu_device)).sum().backward()
+            torch.cuda.synchronize()
+            return [x.grad.clone() for x in f] + [a.grad.clone(), t.grad.clone()]
+        finally:
+            ops._CHAIN_SPLIT, ops.chain_aux_stream = old
+
+    from deep_visual_slam_amd import gradsink
+    seen, orig = [], gradsink.set_pending
+    gradsink.set_pending = lambda t, ev: (seen.append(t.data_ptr()), orig(t, ev))[1]
+    try:
+        one, two = run(False), run(True)
+    finally:
+        gradsink.set_pending = orig
+    assert len(seen) == 5                                 # d disp_1..3 and the two d T were handed out with events
+    for g1, g2 in zip(one, two):
+        assert torch.isfinite(g2).all()
+        assert float((g1 - g2).abs().max()) <= 1e-6 * float(g1.abs().max()) + 1e-12
