@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
 MAX_SCALES = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = C.c_void_p
 

@@ -116,7 +116,7 @@ int dvs_profile_read(int slot, double* total_ms, long* launches) {
 
 const char* dvs_last_error(void) { return dvs::err_buf(); }
 
-int dvs_abi_version(void) { return 3; }
+int dvs_abi_version(void) { return 4; }
 
 const char* dvs_arch(void) { return "gfx950"; }
 
