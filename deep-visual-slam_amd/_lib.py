@@ -63,6 +63,8 @@ _SIGNATURES = {
     "dvs_conv2d_head_bwd": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp]),
     "dvs_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_upsample2x_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_upsample2x_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_bn_fwd": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),

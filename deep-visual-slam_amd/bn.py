@@ -12,6 +12,11 @@ from ._lib import check, ptr
 CL = torch.channels_last
 
 
+def _nn_generation_bump():
+    from . import nn_ops
+    nn_ops.bump_generation()
+
+
 def _finalize_groups(stats, count, bn, groups):
     """stats [G][2][C] (sum, sum of squares per sub-batch) -> [G][4][C] = scale, shift, mean, invstd, one launch;
     running statistics and num_batches_tracked are updated as G successive forward calls of nn.BatchNorm2d in
@@ -22,6 +27,8 @@ def _finalize_groups(stats, count, bn, groups):
     nbt = bn.num_batches_tracked if train_stats else None
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
+    if train_stats:
+        _nn_generation_bump()
     check(_lib.lib().dvs_bn_finalize(stats.data_ptr(), float(count), ptr(bn.weight), ptr(bn.bias),
                                      ptr(bn.running_mean) if train_stats else None,
                                      ptr(bn.running_var) if train_stats else None,
@@ -128,6 +135,8 @@ def bn_act(y, bn, stats, relu=False, residual=None, res_bn=None, res_stats=None,
     nbt = bn.num_batches_tracked if train_stats else None
     if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
         raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
+    if train_stats:
+        _nn_generation_bump()          # the kernel updates running_mean / running_var through raw pointers
     stat_args = (stats, count, bn.running_mean if train_stats else None, bn.running_var if train_stats else None,
                  bn.momentum if bn.momentum is not None else 0.1, bn.eps, nbt)
     res_fin = None
@@ -137,3 +146,65 @@ def bn_act(y, bn, stats, relu=False, residual=None, res_bn=None, res_stats=None,
             res_fin = _finalize_groups(res_stats, count, res_bn, groups)
     return _BNAct.apply(y, bn.weight, bn.bias, residual, res_bn.weight if res_bn is not None else None,
                         res_bn.bias if res_bn is not None else None, stat_args, res_fin, relu, groups)
+
+
+class _AffineAct(torch.autograd.Function):
+    """z = act(y * scale[c] + shift[c] [+ residual]) on NHWC tensors -- an eval-mode BatchNorm2d (running statistics) with
+    the BasicBlock tail, differentiable w.r.t. y, scale, shift and residual.  Same kernels as the training path with the
+    statistics frozen: dvs_bn_apply_fwd forward; backward = dvs_bn_bwd_reduce with (mean, invstd) = (0, 1), which yields
+    du = dz * [z > 0], sum(du) = d shift and sum(du * y) = d scale, then dvs_bn_bwd_apply with zero sums and gamma = scale,
+    which is dy = scale * du."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift, residual, relu):
+        B, C, H, W = y.shape
+        M = B * H * W
+        scale, shift = scale.contiguous(), shift.contiguous()
+        z = torch.empty_like(y)
+        check(_lib.lib().dvs_bn_apply_fwd(y.data_ptr(), ptr(scale), ptr(shift), residual.data_ptr() if residual is not None else None,
+                                          None, None, z.data_ptr(), M, C, int(relu), 1, _lib.stream()), "dvs_bn_apply_fwd")
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(y, scale, z if relu else None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, scale, z = ctx.saved_tensors
+        l = _lib.lib()
+        B, C, H, W = y.shape
+        M = B * H * W
+        dz = dz if dz.is_contiguous(memory_format=CL) else dz.contiguous(memory_format=CL)
+        st = _lib.stream()
+        zero_one = torch.zeros(3, C, device=y.device, dtype=torch.float32)      # rows: mean = 0, invstd = 1, zero sums (x2 below)
+        zero_one[1].fill_(1.0)
+        zeros2 = torch.zeros(2, C, device=y.device, dtype=torch.float32)
+        sums = torch.zeros(2, C, device=y.device, dtype=torch.float32)
+        du = torch.empty_like(y) if ctx.relu else dz
+        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, 1) // 4, device=y.device, dtype=torch.float32)
+        check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(), zero_one[0].data_ptr(),
+                                  zero_one[1].data_ptr(), du.data_ptr() if ctx.relu else None, sums.data_ptr(), ptr(ws), M, C, 1, st),
+              "dvs_bn_bwd_reduce")
+        dy = torch.empty_like(y)
+        check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), zero_one[0].data_ptr(), zero_one[1].data_ptr(), ptr(scale),
+                                 zeros2.data_ptr(), dy.data_ptr(), M, C, None, None, 1, st), "dvs_bn_bwd_apply")
+        return dy, sums[1], sums[0], (du if ctx.has_res else None), None
+
+
+def affine_supported(C):
+    return C % 4 == 0 and 256 % (C // 4) == 0
+
+
+def affine_act(y, scale, shift, relu=False, residual=None):
+    """act(y * scale + shift [+ residual]); scale / shift are [C] tensors (eval-mode BatchNorm as an affine map)."""
+    if not y.is_cuda:
+        raise _lib.DvsError("affine_act: GPU tensors only; this package has no CPU path")
+    C = y.shape[1]
+    if not affine_supported(C):
+        raise _lib.DvsError("affine_act: C %% 4 == 0 and C/4 dividing 256 required (got C = %d)" % C)
+    y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
+    if residual is not None:
+        residual = residual if residual.is_contiguous(memory_format=CL) else residual.contiguous(memory_format=CL)
+        if residual.shape != y.shape:
+            raise _lib.DvsError("affine_act: residual shape %s != %s" % (tuple(residual.shape), tuple(y.shape)))
+    return _AffineAct.apply(y, scale, shift, residual, relu)

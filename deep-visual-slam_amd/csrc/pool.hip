@@ -85,6 +85,35 @@ inline unsigned pool_grid(size_t n) {
     return (unsigned)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
 }
 
+
+// model/layers.py:196-199 `upsample` as a standalone operator: y[b, 2y+dy, 2x+dx, c] = x[b, y, x, c]; backward = 2x2 sum.
+// One lane per (INPUT pixel, 4 channels): one 16-byte load, four 16-byte stores (forward) or the reverse.
+__global__ __launch_bounds__(PNT) void upsample2x_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H,
+                                                         int W, int C, int backward) {
+    const int cv = C >> 2;
+    const size_t n = (size_t)B * H * W * cv;
+    for (size_t i = (size_t)blockIdx.x * PNT + threadIdx.x; i < n; i += (size_t)gridDim.x * PNT) {
+        const int c4 = (int)(i % cv);
+        size_t pix = i / cv;
+        const int x = (int)(pix % W);
+        pix /= W;
+        const int y = (int)(pix % H), b = (int)(pix / H);
+        const size_t lo = (((size_t)b * H + y) * W + x) * C + c4 * 4;
+        const size_t hi = (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c4 * 4;
+        const size_t row = (size_t)2 * W * C;
+        if (!backward) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + lo);
+            *reinterpret_cast<f32x4*>(dst + hi) = v;
+            *reinterpret_cast<f32x4*>(dst + hi + C) = v;
+            *reinterpret_cast<f32x4*>(dst + hi + row) = v;
+            *reinterpret_cast<f32x4*>(dst + hi + row + C) = v;
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + hi), bq = *reinterpret_cast<const f32x4*>(src + hi + C);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + hi + row), d = *reinterpret_cast<const f32x4*>(src + hi + row + C);
+            *reinterpret_cast<f32x4*>(dst + lo) = (a + bq) + (c + d);
+        }
+    }
+}
 }  // namespace
 
 extern "C" {
@@ -105,6 +134,20 @@ int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, i
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(pool_grid(n)), dim3(PNT), 0, static_cast<hipStream_t>(stream), dy,
                        reinterpret_cast<const unsigned*>(idx), dx, B, H, W, C, Ho, Wo);
     return dvs::check_launch("dvs_maxpool3x3s2_bwd");
+}
+
+int dvs_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    DVS_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_upsample2x_fwd: bad argument");
+    const size_t n = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(pool_grid(n)), dim3(PNT), 0, static_cast<hipStream_t>(stream), x, y, B, H, W, C, 0);
+    return dvs::check_launch("dvs_upsample2x_fwd");
+}
+
+int dvs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    DVS_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_upsample2x_bwd: bad argument");
+    const size_t n = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(pool_grid(n)), dim3(PNT), 0, static_cast<hipStream_t>(stream), dy, dx, B, H, W, C, 1);
+    return dvs::check_launch("dvs_upsample2x_bwd");
 }
 
 }  // extern "C"

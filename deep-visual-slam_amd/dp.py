@@ -181,30 +181,69 @@ class GradSync:
         return 1.0 / self.world
 
 
-class FusedAdam:
-    """torch.optim.Adam(params, lr, betas, eps) semantics on the flat arena (dvs_adam_step)."""
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps) semantics on the flat arena (dvs_adam_step): one pass over
+    param / grad / exp_avg / exp_avg_sq instead of the reference's foreach Adam over 244 tensors (vo/train.py:114-117,192).
 
-    def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    It IS a torch.optim.Optimizer: LR schedulers (`PolynomialLR(self.optimizer, ...)`, vo/train.py:120-124) accept it and
+    drive `param_groups[0]["lr"]`; `state_dict()` / `load_state_dict()` speak torch.optim.Adam's per-parameter layout, so
+    the reference's `mono_optimizer_state_dict` checkpoints (vo/train.py:383-390) load here and checkpoints written here
+    resume in the reference trainer.  `params` fixes the parameter numbering of that layout: pass what the reference passes
+    to Adam, `list(depth_net.parameters()) + list(pose_net.parameters())` (the unused `fc` tensors have no arena slot and,
+    as in torch, no state because they never receive a gradient); default = the arena's own order."""
+
+    def __init__(self, flat, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, params=None):
         self.flat = flat
-        self.lr, self.betas, self.eps = lr, betas, eps
+        self._slot = {id(p): i for i, p in enumerate(flat.tensors)}
+        plist = list(params) if params is not None else list(flat.tensors)
+        missing = [i for i, p in enumerate(flat.tensors) if id(p) not in {id(q) for q in plist}]
+        if missing:
+            raise ValueError("FusedAdam: %d arena tensors are missing from `params`" % len(missing))
+        super().__init__([{"params": plist}], dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
+                                                  maximize=False, foreach=None, capturable=False, differentiable=False,
+                                                  fused=None))
         self.exp_avg = torch.zeros_like(flat.params)
         self.exp_avg_sq = torch.zeros_like(flat.params)
         self.step_count = 0
-        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps}]   # scheduler-compatible view
         # data-gradient weight packs of the arena's convolutions, refreshed in one launch after every step
         from . import conv as _conv
         self.packed = _conv.PackedWeights(flat.tensors)
         self.packed.repack()
 
-    def step(self, grad_scale=1.0, zero_grad=True):
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, zero_grad=False):
+        """One Adam update of every arena tensor.  grad_scale: 1/world_size after a sum all-reduce (GradSync.grad_scale);
+        zero_grad=True clears the gradient arena in the same pass (the next step's `optimizer.zero_grad()` is then free)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         self.step_count += 1
         gradsink.join()                      # weight gradients accumulated on side streams
-        lr = self.param_groups[0]["lr"]
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise _lib.DvsError("FusedAdam: weight_decay / amsgrad / maximize are not implemented (the reference trains "
+                                "with plain Adam, vo/train.py:114-117)")
         f = self.flat
+        f.reattach()                         # a caller's zero_grad(set_to_none=True) detaches .grad from the arena
         check(_lib.lib().dvs_adam_step(ptr(f.params), ptr(f.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                       f.numel, lr, self.betas[0], self.betas[1], self.eps, self.step_count,
+                                       f.numel, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], self.step_count,
                                        grad_scale, int(zero_grad), _lib.stream()), "dvs_adam_step")
+        from . import nn_ops
+        nn_ops.bump_generation()             # the weights changed behind torch's version counters: folded-BN caches are stale
         self.packed.repack()
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the gradient arena.  `set_to_none` is accepted for signature compatibility and ignored: the gradients are
+        persistent views of one arena that the kernels accumulate into (gradient sinks), never freed."""
+        gradsink.join()
+        self.flat.reattach()
+        self.flat.zero_grad()
 
     def __del__(self):
         try:
@@ -212,15 +251,70 @@ class FusedAdam:
         except Exception:
             pass
 
+    # ---- torch.optim.Adam-compatible checkpoints -------------------------------------------------------------
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": self.param_groups}
+        """{"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} exactly as torch.optim.Adam over
+        `params` would produce (tensors cloned out of the arena in the parameters' logical shapes)."""
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        plist = self.param_groups[0]["params"]
+        group["params"] = list(range(len(plist)))
+        state = {}
+        if self.step_count > 0:
+            f = self.flat
+            for idx, p in enumerate(plist):
+                i = self._slot.get(id(p))
+                if i is None:
+                    continue                 # e.g. encoder.fc.*: never receives a gradient, so torch keeps no state either
+                o = f.offsets[i]
+                state[idx] = {"step": torch.tensor(float(self.step_count)),
+                              "exp_avg": f._view(self.exp_avg, p, o).detach().clone(memory_format=torch.contiguous_format),
+                              "exp_avg_sq": f._view(self.exp_avg_sq, p, o).detach().clone(memory_format=torch.contiguous_format)}
+        return {"state": state, "param_groups": [group]}
 
+    @torch.no_grad()
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups = sd["param_groups"]
+        """Accepts torch.optim.Adam's layout (a reference checkpoint's `mono_optimizer_state_dict`) and this class's
+        round-1 flat layout ({"step", "exp_avg", "exp_avg_sq", "param_groups"})."""
+        if "state" not in sd:                                    # flat layout
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            for k in ("lr", "betas", "eps"):
+                if k in sd["param_groups"][0]:
+                    self.param_groups[0][k] = sd["param_groups"][0][k]
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1:
+            raise ValueError("FusedAdam.load_state_dict: expected one parameter group, got %d" % len(groups))
+        plist = self.param_groups[0]["params"]
+        ids = list(groups[0]["params"])
+        if len(ids) != len(plist):
+            raise ValueError("FusedAdam.load_state_dict: checkpoint has %d parameters, optimiser has %d" % (len(ids), len(plist)))
+        f = self.flat
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for pos, key in enumerate(ids):
+            st = sd["state"].get(key)
+            if st is None:
+                continue
+            p = plist[pos]
+            i = self._slot.get(id(p))
+            if i is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("FusedAdam.load_state_dict: state %s has shape %s, parameter has %s"
+                                 % (key, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            o = f.offsets[i]
+            f._view(self.exp_avg, p, o).copy_(st["exp_avg"])
+            f._view(self.exp_avg_sq, p, o).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam.load_state_dict: parameters with different step counts %s (one fused pass keeps one)" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        for k, v in groups[0].items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v
 
 
 def profile_enable(on=True):

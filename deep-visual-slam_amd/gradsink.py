@@ -98,11 +98,18 @@ def set_pending(tensor, event):
 
 
 def wait_pending(tensor):
-    """The current stream waits for the producer of `tensor`, if one was registered (loss-chain backward by scale)."""
+    """The current stream waits for the producer of `tensor`, if one was registered (loss-chain backward by scale).
+    Fail safe: while gradients are pending and `tensor` is not one of them (autograd summed or copied it on the way --
+    a second consumer, a hook), wait for ALL pending producers rather than for none."""
     if _pending and tensor is not None:
         ev = _pending.pop(tensor.data_ptr(), None)
+        cur = torch.cuda.current_stream()
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            cur.wait_event(ev)
+        else:
+            for e in _pending.values():
+                cur.wait_event(e)
+            _pending.clear()
 
 
 def clear_pending():

@@ -13,15 +13,38 @@ This module adds the two optional extras a real-time loop wants:
 """
 import torch
 
-from . import _lib
+from . import _lib, nn_ops
+
+
+def _fold_snapshot():
+    """(generation, references to every folded-BatchNorm tensor currently cached).  A captured graph holds raw pointers to
+    those tensors; nn_ops._fold_cache may replace an entry later (new weights, optimiser step) and the old tensors would
+    be freed under the graph -- the holder keeps them alive, the generation tells a replay that they are stale."""
+    return nn_ops.generation(), [(w, b) for (_, w, b) in nn_ops._fold_cache.values()]
+
+
+class _WeightsWatch:
+    """torch-visible modification state of every parameter / buffer of some networks (in-place torch updates,
+    load_state_dict bump `_version`).  One attribute read per tensor and replay: ~25 us for both networks."""
+
+    def __init__(self, *nets):
+        self.tensors = [t for net in nets for t in list(net.parameters()) + list(net.buffers())]
+        self.ptrs = tuple(t.data_ptr() for t in self.tensors)
+        self.seen = self.versions()
+
+    def versions(self):
+        return sum(t._version for t in self.tensors)
+
+    def changed(self):
+        return self.versions() != self.seen
 
 
 class Graphed:
     """net(x) for one fixed input shape, replayed from a captured HIP graph.
 
-    The returned tensors are the graph's static outputs: consume (or clone) them before the next call.  The network's
-    weights are read at replay time, but the BatchNorm fold is part of the capture: call `refresh()` after loading new
-    weights."""
+    The returned tensors are the graph's static outputs: consume (or clone) them before the next call.  The BatchNorm fold is part
+    of the capture; the object keeps the folded tensors alive and re-captures by itself when the weights or buffers
+    change (torch version counters, nn_ops.generation() for the library's raw-pointer writers)."""
 
     def __init__(self, net, example, warmup=3):
         if net.training:
@@ -44,10 +67,18 @@ class Graphed:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = self.net(self.static_in)
+        self._gen, self._held = _fold_snapshot()
+        self._watch = _WeightsWatch(self.net)
+
+    def stale(self):
+        """True when the weights or BatchNorm buffers changed since the capture (the fold is part of the graph)."""
+        return self._gen != nn_ops.generation() or self._watch.changed()
 
     def __call__(self, x):
         if x.shape != self.static_in.shape:
             raise _lib.DvsError("Graphed: captured for input %s, got %s" % (tuple(self.static_in.shape), tuple(x.shape)))
+        if self.stale():
+            self.refresh()                   # re-fold and re-capture: never replay pointers to a replaced fold
         self.static_in.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out
@@ -78,9 +109,17 @@ class FramePredictor:
                     self._run(self.s_target, self.s_pair)
             torch.cuda.current_stream().wait_stream(warm)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph):
-                self.static_out = self._run(self.s_target, self.s_pair)
+            self._capture()
+
+    def _capture(self):
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = self._run(self.s_target, self.s_pair)
+        self._gen, self._held = _fold_snapshot()
+        self._watch = _WeightsWatch(self.depth_net, self.pose_net)
+
+    def stale(self):
+        return self.graph is not None and (self._gen != nn_ops.generation() or self._watch.changed())
 
     def _run(self, target, pair):
         main = torch.cuda.current_stream()
@@ -97,6 +136,11 @@ class FramePredictor:
         if self.graph is None:
             with torch.no_grad():
                 return self._run(target, pair)
+        if self.stale():
+            with torch.no_grad():
+                self._run(self.s_target, self.s_pair)           # refold eagerly (fills the cache), then re-capture
+            torch.cuda.synchronize()
+            self._capture()
         self.s_target.copy_(target, non_blocking=True)
         self.s_pair.copy_(pair, non_blocking=True)
         self.graph.replay()

@@ -20,25 +20,61 @@ from .layers import SSIM, BackprojectDepth, Project3D
 
 
 class LazyOutputs(dict):
-    """`outputs` dict whose view-synthesis tensors are produced on first access."""
+    """`outputs` dict whose view-synthesis tensors are produced on first need.  Every read access a caller of the
+    reference's dict could make -- `[]`, `in`, `.get()`, iteration, `.keys()/.items()/.values()`, `len()`, `==`, copying
+    -- sees the full schema of vo/learner_new.py:132-172,241: a key that is already present is answered without
+    materialising, anything else fills the lazy entries first."""
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self._thunk = None
-
-    def __missing__(self, key):
-        if self._thunk is not None:
-            thunk, self._thunk = self._thunk, None
-            thunk(self)
-            if dict.__contains__(self, key):
-                return dict.__getitem__(self, key)
-        raise KeyError(key)
 
     def materialize(self):
         if self._thunk is not None:
             thunk, self._thunk = self._thunk, None
             thunk(self)
         return self
+
+    def __missing__(self, key):
+        if self._thunk is not None:
+            self.materialize()
+            if dict.__contains__(self, key):
+                return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (self._thunk is not None and dict.__contains__(self.materialize(), key))
+
+    def get(self, key, default=None):
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        return dict.get(self.materialize(), key, default)
+
+    def __iter__(self):
+        return dict.__iter__(self.materialize())
+
+    def __len__(self):
+        return dict.__len__(self.materialize())
+
+    def keys(self):
+        return dict.keys(self.materialize())
+
+    def items(self):
+        return dict.items(self.materialize())
+
+    def values(self):
+        return dict.values(self.materialize())
+
+    def copy(self):
+        return dict(self.materialize())
+
+    def __eq__(self, other):
+        return dict.__eq__(self.materialize(), other)
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (dict(self.materialize()),))
 
 
 class MonodepthTrainer:

@@ -1,28 +1,22 @@
 """Network primitives used by ResnetEncoder / DepthNet / PoseNet.
 
-Every primitive is GPU-only and keeps activations in channels_last (NHWC) memory.  The convolution
-engine is selected by DVS_CONV_BACKEND:
-  "hip"    (default) hand-written gfx950 implicit-GEMM kernels of libdvslam_hip.so wherever they cover
-           the shape (everything except the 1- and 6-channel heads);
-  "miopen" PyTorch-ROCm's library convolution composed with eager pad / upsample / cat / activation --
-           bring-up and A/B baseline only.  Neither choice ever runs on the CPU.
+Every primitive is GPU-only, keeps activations in channels_last (NHWC) memory and runs on the hand-written gfx950
+kernels of libdvslam_hip.so.  There is no library (MIOpen / ATen) convolution, BatchNorm, pooling or padding path in
+the product: a shape the kernels do not cover raises `DvsError` instead of silently leaving the MI355X-native path
+(the A/B composition against PyTorch-ROCm's library ops lives in tools/miopen_compose.py, outside the package).
 """
-import os
-
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from . import conv as _conv
 
 CL = torch.channels_last
-_ACT = {None: lambda v: v, "relu": F.relu, "elu": F.elu, "sigmoid": torch.sigmoid}
 
 
 def _require_gpu(x, who):
     if not x.is_cuda:
         raise _lib.DvsError("%s: GPU tensors only (got %s); this package has no CPU path" % (who, x.device))
-    _lib.lib()  # the HIP library must be present even when a library conv is selected
+    _lib.lib()
 
 
 _batch_groups = 1
@@ -45,10 +39,6 @@ class batch_groups:
         _batch_groups = self.prev
 
 
-def conv_backend():
-    return os.environ.get("DVS_CONV_BACKEND", "hip")
-
-
 def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
            planar_norm=None):
     """act(conv(pad(input), weight) + bias) where input is x, upsample2x(x) (upsample=True) or
@@ -57,38 +47,45 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     with (x - 0.45) / 0.225 folded in (model/resnet_encoder.py:102-103)."""
     _require_gpu(x, "conv2d")
     planar = planar_norm is not None
-    if conv_backend() == "hip":
-        if _conv.supported(x, weight, x2, planar, upsample):
-            return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
-                                planar_norm=planar_norm)
-        if _conv.head_supported(x, weight, stride, padding, reflect_pad, x2, upsample, planar):
-            return _conv.head_conv2d(x, weight, bias, padding, reflect_pad, act)
-    # library path (also serves the 1- and 6-channel heads)
-    if planar:
-        sc, sh = planar_norm
-        x = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
-    if upsample or x2 is not None:
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-    if x2 is not None:
-        x = torch.cat([x, x2], 1)
-    if reflect_pad:
-        x = F.pad(x, (reflect_pad,) * 4, mode="reflect")
-    return _ACT[act](F.conv2d(x, weight, bias, stride, padding))
+    if _conv.supported(x, weight, x2, planar, upsample):
+        return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
+                            planar_norm=planar_norm)
+    if _conv.head_supported(x, weight, stride, padding, reflect_pad, x2, upsample, planar):
+        return _conv.head_conv2d(x, weight, bias, padding, reflect_pad, act)
+    raise _lib.DvsError("conv2d: no gfx950 kernel for weight %s on input %s (stride %d, pad %d, reflect %d, concat %s, "
+                        "upsample %s): channel counts must be multiples of 4 (or a 1/2/6/8-channel stride-1 head)"
+                        % (tuple(weight.shape), tuple(x.shape), stride, padding, reflect_pad, x2 is not None, upsample))
 
 
+# Folded-BatchNorm cache.  The fold depends on five tensors (conv weight, gamma, beta, running_mean, running_var); the
+# repo's own writers update them through raw pointers (dvs_adam_step on the flat arena, dvs_bn_fwd / dvs_bn_finalize on
+# the running statistics), which torch's `_version` counters never see -- so every such writer bumps `_generation`
+# (dp.FusedAdam.step, bn.bn_act / _finalize_groups in training mode) and the cache key includes it.
 _fold_cache = {}
+_generation = 0
+
+
+def bump_generation():
+    """Called by every code path that modifies parameters or BatchNorm buffers behind torch's back."""
+    global _generation
+    _generation += 1
+
+
+def generation():
+    return _generation
 
 
 def folded_bn(weight, bn):
     """(w', b') with an eval-mode BatchNorm2d folded into the convolution in front of it:
     bn(conv(x, w)) = conv(x, w * s) + (beta - running_mean * s),  s = gamma / sqrt(running_var + eps).
-    Cached per weight tensor and refreshed when any of the five tensors is modified in place (optimiser step,
-    load_state_dict), so an inference loop pays for the fold once."""
+    Cached per weight tensor and refreshed when any of the five tensors is modified -- in place through torch
+    (`_version`: torch optimisers, load_state_dict) or through the library's raw-pointer writers (`_generation`) --
+    so an inference loop pays for the fold once."""
     gamma = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
     beta = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_var)
     key = id(weight)
     ver = (weight._version, gamma._version, beta._version, bn.running_mean._version, bn.running_var._version,
-           weight.data_ptr(), bn.running_mean.data_ptr(), bn.eps)
+           weight.data_ptr(), bn.running_mean.data_ptr(), bn.eps, _generation)
     hit = _fold_cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1], hit[2]
@@ -105,16 +102,33 @@ def inference_mode(bn):
     return (not bn.training) and bn.track_running_stats and bn.running_mean is not None and not torch.is_grad_enabled()
 
 
+def _eval_affine(bn):
+    """Eval-mode BatchNorm as the per-channel affine map it is: (scale, shift) as differentiable functions of gamma / beta
+    (tiny [C] tensor arithmetic; the [M,C] passes are dvs_bn_* kernels, bn.affine_act)."""
+    if bn.running_mean is None or not bn.track_running_stats:
+        raise _lib.DvsError("BatchNorm without running statistics has no eval-mode form")
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * inv if bn.weight is not None else inv
+    shift = -bn.running_mean * scale
+    if bn.bias is not None:
+        shift = shift + bn.bias
+    return scale, shift
+
+
 def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None):
     """relu(bn(conv(x)) + residual') -- the conv -> BatchNorm2d -> (+identity) -> ReLU groups of torchvision's
     BasicBlock / stem (model/resnet_encoder.py:100-111).  `residual` is the identity tensor; `res` =
     (weight, bn, stride) describes the 1x1 downsample branch conv -> bn applied to `residual` instead.
-    HIP path: the conv epilogue accumulates the batch statistics, BN + add + ReLU is one fused pass."""
+    Training: the conv epilogue accumulates the batch statistics, BN + add + ReLU is one fused pass.
+    eval() + no_grad: BatchNorm folded into the weights, one kernel per conv.
+    eval() with autograd (validation loss without no_grad, frozen-BN fine-tuning): BatchNorm is a per-channel affine
+    map applied by the same BN kernels with fixed statistics; batch grouping is irrelevant there."""
     _require_gpu(x, "conv_bn_act")
     from . import bn as _bn
     planar = planar_norm is not None
-    if (inference_mode(bn) and conv_backend() == "hip" and _conv.supported(x, weight, None, planar)
-            and (res is None or (inference_mode(res[1]) and _conv.supported(residual, res[0])))):
+    if not _conv.supported(x, weight, None, planar) or (res is not None and not _conv.supported(residual, res[0])):
+        raise _lib.DvsError("conv_bn_act: no gfx950 kernel for weight %s on input %s" % (tuple(weight.shape), tuple(x.shape)))
+    if inference_mode(bn) and (res is None or inference_mode(res[1])):
         # inference (vo/predict.py:20-42,63-86: .eval() + torch.no_grad()): BatchNorm folded into the weights, bias +
         # identity + ReLU in the conv epilogue -- one kernel per conv, no normalisation passes
         sc, sh = planar_norm if planar else (None, None)
@@ -124,34 +138,23 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
         w_f, b_f = folded_bn(weight, bn)
         return _conv.conv2d_forward(x, w_f, b_f, stride, padding, act="relu" if relu else None, in_scale=sc, in_shift=sh,
                                     nchw_planar=planar, residual=residual)
-    fused = (conv_backend() == "hip" and _conv.supported(x, weight, None, planar) and _bn.supported_c(weight.shape[0], bn)
-             and (res is None or (_conv.supported(residual, res[0]) and _bn.supported_c(res[0].shape[0], res[1]))))
-    G = _batch_groups
-    if G != 1 and not fused:
-        raise _lib.DvsError("batch_groups(%d) needs the fused HIP conv + BatchNorm path" % G)
-    if fused:
-        y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G)
+    if not bn.training:
+        # eval mode with autograd enabled: running statistics, differentiable w.r.t. x, conv weights, gamma, beta
+        y = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm)
         if res is not None:
-            yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G)
-            return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G)
-        return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
-    y = conv2d(x, weight, None, stride, padding, planar_norm=planar_norm)
+            rs, rh = _eval_affine(res[1])
+            residual = _bn.affine_act(_conv.conv2d(residual, res[0], None, res[2], 0), rs, rh)
+        sc, sh = _eval_affine(bn)
+        return _bn.affine_act(y, sc, sh, relu=relu, residual=residual)
+    if not _bn.supported_c(weight.shape[0], bn) or (res is not None and not _bn.supported_c(res[0].shape[0], res[1])):
+        raise _lib.DvsError("conv_bn_act: the fused BatchNorm kernels cover affine BatchNorm2d with C % 4 == 0 and C/4 "
+                            "dividing 256 (got C = %d)" % weight.shape[0])
+    G = _batch_groups
+    y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G)
     if res is not None:
-        residual = batch_norm(conv2d(residual, res[0], None, res[2], 0), res[1])
-    return batch_norm(y, bn, relu=relu, residual=residual)
-
-
-def batch_norm(x, bn, relu=False, residual=None):
-    """nn.BatchNorm2d forward (batch statistics + running-stat update in training mode), optionally
-    followed by `+ residual` and ReLU: the BasicBlock tail."""
-    _require_gpu(x, "batch_norm")
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                     bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y, inplace=True) if relu else y
+        yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G)
+        return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G)
+    return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
 
 
 class _MaxPool3x3s2(torch.autograd.Function):
@@ -183,12 +186,36 @@ class _MaxPool3x3s2(torch.autograd.Function):
 
 def max_pool_3x3_s2(x):
     _require_gpu(x, "max_pool")
-    if x.shape[1] % 4 == 0 and x.dtype == torch.float32:
-        return _MaxPool3x3s2.apply(x)
-    return F.max_pool2d(x, 3, 2, 1)
+    if x.shape[1] % 4 or x.dtype != torch.float32:
+        raise _lib.DvsError("max_pool_3x3_s2: fp32 tensors with a multiple of 4 channels only (got %s %s)" % (x.dtype, tuple(x.shape)))
+    return _MaxPool3x3s2.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    """Nearest-neighbour 2x upsampling of an NHWC tensor (dvs_upsample2x_fwd / _bwd; the backward is the 2x2 block sum)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32, memory_format=CL)
+        _lib.check(_lib.lib().dvs_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _lib.stream()), "dvs_upsample2x_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
+        _lib.check(_lib.lib().dvs_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _lib.stream()), "dvs_upsample2x_bwd")
+        return dx
 
 
 def upsample_nearest2x(x):
-    """model/layers.py:196-199."""
+    """model/layers.py:196-199 as a standalone operator (the decoder itself gathers the upsampled tensor inside its
+    convolution and never materialises it)."""
     _require_gpu(x, "upsample")
-    return F.interpolate(x, scale_factor=2, mode="nearest")
+    if x.shape[1] % 4 or x.dtype != torch.float32:
+        raise _lib.DvsError("upsample: fp32 tensors with a multiple of 4 channels only (got %s %s)" % (x.dtype, tuple(x.shape)))
+    return _Upsample2x.apply(x)

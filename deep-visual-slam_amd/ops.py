@@ -185,7 +185,9 @@ class _LossChain(torch.autograd.Function):
             ev_t.record(aux)
         for t in d_T:
             gradsink.set_pending(t, ev_t)
-        for t in d_disps[1:] + d_T + [bwd_partials, d_losses, sel, stats] + list(disps):
+        # everything the aux-stream kernels read or write must outlive them in the caching allocator's eyes -- including
+        # the contiguous copies _f32c may have made of the images / intrinsics / poses in the forward
+        for t in d_disps[1:] + d_T + [bwd_partials, d_losses, sel, stats, target, src_l, src_r, K, inv_K, T_l, T_r] + list(disps):
             t.record_stream(aux)
         return (None, None, None, None, None, None, d_T[0], d_T[1], None, *d_disps)
 
@@ -200,8 +202,10 @@ def loss_chain(target, src_l, src_r, K, inv_K, T_l, T_r, disps, noise=None, seed
     # consumers are the nodes that wait for them: the disparity heads and the pose-matrix Function
     def fn_name(t):
         return type(t.grad_fn).__name__ if isinstance(t, torch.Tensor) and t.grad_fn is not None else None
-    opts["split_ok"] = (all(fn_name(d) == "_HeadConvBackward" for d in disps[1:])
-                        and all(fn_name(t) in ("_PoseToMatBackward", None) for t in (T_l, T_r)))
+    def no_hooks(t):
+        return not getattr(t, "_backward_hooks", None)
+    opts["split_ok"] = (all(fn_name(d) == "_HeadConvBackward" and no_hooks(d) for d in disps[1:])
+                        and all(fn_name(t) in ("_PoseToMatBackward", None) and no_hooks(t) for t in (T_l, T_r)))
     out = _LossChain.apply(opts, target, src_l, src_r, K, inv_K, T_l, T_r, noise, *disps)
     losses, sel, flat = out[0], out[1], out[2:]
     extras = []

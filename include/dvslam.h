@@ -167,6 +167,11 @@ int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const fl
  * ------------------------------------------------------------------------------------------- */
 int dvs_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, void* stream);
 int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, void* stream);
+/* `upsample` of model/layers.py:196-199 (F.interpolate(scale_factor=2, mode="nearest")) as a standalone operator on NHWC
+ * tensors: x, dx [B,H,W,C]; y, dy [B,2H,2W,C]; C % 4 == 0.  The backward is the 2x2 block sum.  (The decoder itself never
+ * materialises the upsampled tensor: dvs_conv_fusion.x2 / C1 gather it inside the convolution.) */
+int dvs_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int dvs_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1  training-mode BatchNorm2d (+ residual add, + ReLU) of the ResNet BasicBlocks on NHWC tensors

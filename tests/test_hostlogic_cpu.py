@@ -1,0 +1,192 @@
+"""Host-side logic that needs no GPU: the lazy `outputs` dict, FusedAdam as a torch.optim.Optimizer (scheduler
+acceptance, torch.optim.Adam-compatible checkpoints), the folded-BatchNorm generation counter, and the loud failure of
+every primitive off the GPU / outside the kernels' shape coverage (no library fallback in the product)."""
+import pickle
+
+import pytest
+import torch
+
+
+# ------------------------------------------------------------------------------------------ LazyOutputs
+def _lazy():
+    from deep_visual_slam_amd.learner_new import LazyOutputs
+    out = LazyOutputs({("disp", 0): 1, ("cam_T_cam", 0, -1): 2})
+    calls = []
+
+    def fill(o):
+        calls.append(1)
+        o[("depth", 0)] = 3
+        o["identity_selection/0"] = 4
+
+    out._thunk = fill
+    return out, calls
+
+
+def test_lazy_outputs_present_keys_do_not_materialise():
+    out, calls = _lazy()
+    assert out[("disp", 0)] == 1 and ("disp", 0) in out and out.get(("cam_T_cam", 0, -1)) == 2
+    assert not calls
+
+
+@pytest.mark.parametrize("access", ["getitem", "contains", "get", "iter", "keys", "items", "values", "len", "copy", "dict", "eq",
+                                    "pickle"])
+def test_lazy_outputs_every_read_access_sees_the_full_schema(access):
+    """vo/learner_new.py:132-172,241 puts these keys into a plain dict; whatever a caller does with it must see them."""
+    out, calls = _lazy()
+    want = {("disp", 0), ("cam_T_cam", 0, -1), ("depth", 0), "identity_selection/0"}
+    if access == "getitem":
+        assert out[("depth", 0)] == 3
+    elif access == "contains":
+        assert ("depth", 0) in out and "nope" not in out
+    elif access == "get":
+        assert out.get("identity_selection/0") == 4 and out.get("nope", 7) == 7
+    elif access == "iter":
+        assert set(iter(out)) == want
+    elif access == "keys":
+        assert set(out.keys()) == want
+    elif access == "items":
+        assert dict(out.items())[("depth", 0)] == 3
+    elif access == "values":
+        assert sorted(out.values()) == [1, 2, 3, 4]
+    elif access == "len":
+        assert len(out) == 4
+    elif access == "copy":
+        assert set(out.copy()) == want
+    elif access == "dict":
+        assert set(dict(out)) == want
+    elif access == "eq":
+        assert out == {("disp", 0): 1, ("cam_T_cam", 0, -1): 2, ("depth", 0): 3, "identity_selection/0": 4}
+    elif access == "pickle":
+        assert set(pickle.loads(pickle.dumps(out))) == want
+    assert calls == [1]
+    with pytest.raises(KeyError):
+        out[("nope", 0)]
+    assert calls == [1]                      # materialised once
+
+
+# ------------------------------------------------------------------------------------------ FusedAdam
+def _two_nets():
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, bias=True), torch.nn.BatchNorm2d(8))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 3))
+    b.add_module("fc", torch.nn.Linear(3, 2))          # stands in for torchvision's unused encoder.fc (no arena slot)
+    return a, b
+
+
+def _fused(a, b, **kw):
+    from deep_visual_slam_amd import dp
+    named = [("0." + n, p) for n, p in a.named_parameters()] + [("1." + n, p) for n, p in b.named_parameters() if not n.startswith("fc.")]
+    flat = dp.FlatParams(named)
+    ref_order = list(a.parameters()) + list(b.parameters())      # what vo/train.py:114-117 hands to Adam
+    return flat, dp.FusedAdam(flat, lr=1e-4, params=ref_order, **kw), ref_order
+
+
+def test_fused_adam_is_an_optimizer_and_takes_the_reference_scheduler():
+    """vo/train.py:120-124: PolynomialLR(self.optimizer, total_iters=epoch, power=0.9)."""
+    a, b = _two_nets()
+    flat, opt, _ = _fused(a, b)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.PolynomialLR(opt, total_iters=10, power=0.9)
+    assert opt.param_groups[0]["initial_lr"] == 1e-4
+    opt.step_count = 1                       # pretend a step happened (the kernel itself needs the GPU)
+    sched.step()
+    assert abs(opt.lr - 1e-4 * (1 - 1 / 10) ** 0.9) < 1e-12
+    assert "last_epoch" in sched.state_dict()
+
+
+def test_fused_adam_state_dict_is_torch_adam_layout_and_round_trips():
+    a, b = _two_nets()
+    flat, opt, order = _fused(a, b)
+    assert opt.state_dict()["state"] == {}                  # like torch: no state before the first step
+    opt.step_count = 3
+    opt.exp_avg.copy_(torch.randn_like(opt.exp_avg))
+    opt.exp_avg_sq.copy_(torch.rand_like(opt.exp_avg_sq))
+    sd = opt.state_dict()
+    # same layout as torch.optim.Adam over the reference's parameter list (the two `fc` tensors have no state)
+    ref = torch.optim.Adam(order, lr=1e-4)
+    for p in order[:-2]:
+        p.grad = torch.zeros_like(p)
+    ref.step()
+    rsd = ref.state_dict()
+    assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+    assert sd["param_groups"][0]["params"] == rsd["param_groups"][0]["params"] == list(range(len(order)))
+    assert set(sd["state"]) == set(rsd["state"]) == set(range(len(order) - 2))
+    for i, p in enumerate(order[:-2]):
+        assert sd["state"][i]["exp_avg"].shape == p.shape and sd["state"][i]["exp_avg"].is_contiguous()
+        assert float(sd["state"][i]["step"]) == 3.0
+    # torch.optim.Adam loads it ...
+    ref.load_state_dict(sd)
+    assert torch.equal(ref.state[order[0]]["exp_avg"], sd["state"][0]["exp_avg"])
+    # ... and a second FusedAdam restores the arena from torch's own state_dict
+    a2, b2 = _two_nets()
+    flat2, opt2, order2 = _fused(a2, b2)
+    opt2.load_state_dict(ref.state_dict())
+    assert opt2.step_count == 3
+    for p_, o_ in zip(flat.tensors, flat.offsets):                # slot by slot (the alignment padding between slots is not state)
+        n_ = p_.numel()
+        assert torch.equal(opt2.exp_avg[o_:o_ + n_], opt.exp_avg[o_:o_ + n_])
+        assert torch.equal(opt2.exp_avg_sq[o_:o_ + n_], opt.exp_avg_sq[o_:o_ + n_])
+    # conv weights are stored [Cout][kh][kw][Cin] in the arena but checkpointed in the logical shape
+    conv_state = sd["state"][0]["exp_avg"]
+    slot = [i for i, t in enumerate(flat.tensors) if t is order[0]][0]
+    o = flat.offsets[slot]
+    assert torch.equal(opt.exp_avg[o:o + conv_state.numel()].view(8, 3, 3, 4).permute(0, 3, 1, 2), conv_state)
+    # round-1 flat layout still loads
+    opt2.load_state_dict({"step": 5, "exp_avg": opt.exp_avg * 2, "exp_avg_sq": opt.exp_avg_sq, "param_groups": [{"lr": 3e-5}]})
+    assert opt2.step_count == 5 and opt2.lr == 3e-5
+
+
+def test_fused_adam_rejects_unsupported_options_and_mismatched_checkpoints():
+    a, b = _two_nets()
+    flat, opt, order = _fused(a, b)
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"state": {}, "param_groups": [{"params": [0, 1]}]})
+    from deep_visual_slam_amd import dp
+    with pytest.raises(ValueError):
+        dp.FusedAdam(flat, params=order[1:])                    # an arena tensor missing from the numbering
+
+
+def test_zero_grad_keeps_the_arena_views():
+    a, b = _two_nets()
+    flat, opt, order = _fused(a, b)
+    flat.grads.fill_(1.0)
+    for p in order:
+        p.grad = None                                            # what the reference's zero_grad(set_to_none=True) does
+    opt.zero_grad(set_to_none=True)
+    assert float(flat.grads.abs().max()) == 0.0
+    for p, o in zip(flat.tensors, flat.offsets):
+        assert p.grad is not None and p.grad.data_ptr() == flat.grads.data_ptr() + 4 * o
+
+
+# ------------------------------------------------------------------------------------------ fold generation
+def test_fold_cache_follows_raw_pointer_writers():
+    """dvs_adam_step / dvs_bn_fwd write weights and running statistics through raw pointers: torch's _version does not
+    move, nn_ops.bump_generation() (called by FusedAdam.step and the training-mode BatchNorm wrappers) must."""
+    from deep_visual_slam_amd import nn_ops
+    torch.manual_seed(0)
+    w = torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    bn = torch.nn.BatchNorm2d(8).eval()
+    w_f, _ = nn_ops.folded_bn(w, bn)
+    assert nn_ops.folded_bn(w, bn)[0] is w_f
+    w.permute(0, 2, 3, 1).view(-1).numpy()[:] *= 0.5                                  # a write torch's version counter does not see
+    v = w._version
+    assert nn_ops.folded_bn(w, bn)[0] is w_f and w._version == v  # stale -- which is exactly the hazard
+    nn_ops.bump_generation()
+    w_g, _ = nn_ops.folded_bn(w, bn)
+    assert w_g is not w_f and torch.allclose(w_g, w / torch.sqrt(bn.running_var + bn.eps).view(-1, 1, 1, 1))
+
+
+# ------------------------------------------------------------------------------------------ no library fallback
+def test_primitives_fail_loudly_without_gpu_or_kernel():
+    from deep_visual_slam_amd import _lib, nn_ops
+    import deep_visual_slam_amd.nn_ops as N
+    src = open(N.__file__).read()
+    for banned in ("F.conv2d", "F.batch_norm", "F.max_pool2d", "F.interpolate", "F.pad", "DVS_CONV_BACKEND"):
+        assert banned not in src, banned
+    x = torch.zeros(1, 16, 8, 8)
+    w = torch.zeros(16, 16, 3, 3)
+    bn = torch.nn.BatchNorm2d(16)
+    for call in (lambda: nn_ops.conv2d(x, w), lambda: nn_ops.conv_bn_act(x, w, bn), lambda: nn_ops.max_pool_3x3_s2(x),
+                 lambda: nn_ops.upsample_nearest2x(x)):
+        with pytest.raises(_lib.DvsError):
+            call()
