@@ -9,9 +9,14 @@ A step = zero_grad -> DepthNet + 2x PoseNet forward -> fused 4-scale view-synthe
 HBM.  Default workload: BASELINE.json configs[2]/[3] per GPU (batch 12, 4 scales,
 ResNet-18, fp32); `--config c2` selects configs[1] (batch 4, single scale).  Weak scaling: the
 per-GPU batch is fixed, `value` is the whole-job frames/s = 3 * B * N / t_step (max over ranks).
-Rank 0 prints one JSON line with `roofline` (dominant hand-written kernel, HIP-event timed inside
-the timed region) and, at N=1, `cpu_baseline` (the oracle's PyTorch-CPU restatement of the same step
-on a bounded sample).
+Rank 0 prints one JSON line with `roofline` (dominant hand-written kernel class; its launches are HIP-event timed
+over 5 further SINGLE-STREAM steps run right after the timed region -- the timed steps overlap four streams, where an
+event pair would measure how long a kernel shared the chip) and, at N=1, `cpu_baseline` (the oracle's PyTorch-CPU
+restatement of the same step at the same batch), `stock_caller` (the literal vo/train.py:173-199 sequence: per-parameter
+torch.optim.Adam, zero_grad(set_to_none=True), five .detach().cpu() per step) and `loss_check` (the first-step loss
+against the committed oracle value, tests/golden/bench_loss.json).  `ms_per_step` is the mean over the K timed steps
+(what `value` is computed from); `median_ms_per_step` is the median of the K per-step intervals taken from events
+recorded on the main stream (BASELINE.md section 2 defines the metric on the median of >= 50 steps: the default K).
 """
 import argparse
 import json
@@ -64,6 +69,78 @@ def gpu_step(trainer, sync, opt, sample):
     sync.finish()
     opt.step(grad_scale=sync.grad_scale, zero_grad=True)
     return losses
+
+
+def build_stock(batch, num_scales, device, rank):
+    """What the UNCHANGED reference caller constructs (vo/train.py:64-117): plain modules, one torch.optim.Adam over
+    list(depth_net.parameters()) + list(pose_net.parameters()); no arena, no gradient sinks, no fused optimiser."""
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    torch.manual_seed(0)
+    depth_net = DepthNet(18, pretrained=False).to(device).train()
+    pose_net = PoseNet(18, pretrained=False, num_input_images=2).to(device).train()
+    opt = torch.optim.Adam(list(depth_net.parameters()) + list(pose_net.parameters()), lr=1e-4)
+    trainer = MonodepthTrainer(depth_net, pose_net, train_config(batch, num_scales), device)
+    trainer.num_scales = num_scales
+    sample = synth.throughput_sample(batch, H, W, rank=rank, device=device)
+    return trainer, opt, sample
+
+
+def stock_step(trainer, opt, sample):
+    """vo/train.py:173-199 train_mono_step, line for line (non-AMP branch)."""
+    opt.zero_grad(set_to_none=True)
+    outputs, losses = trainer.process_batch(sample)
+    total_loss = losses["loss"]
+    total_loss.backward()
+    opt.step()
+    total_loss = total_loss.detach()
+    for key in losses:
+        losses[key] = losses[key].detach().cpu()
+    return total_loss, outputs, losses
+
+
+def time_stock(batch, num_scales, device, rank, steps, warmup):
+    trainer, opt, sample = build_stock(batch, num_scales, device, rank)
+    for _ in range(warmup):
+        stock_step(trainer, opt, sample)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stock_step(trainer, opt, sample)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 3.0 * batch / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": steps,
+            "sequence": "vo/train.py:173-199 unchanged: optimizer.zero_grad(set_to_none=True); process_batch; backward; "
+                        "torch.optim.Adam.step(); losses[k].detach().cpu() x5 (a host sync every step)"}
+
+
+def loss_check(trainer, sample, config):
+    """First-step loss of the seeded bench workload (rank 0) against the committed oracle value."""
+    path = os.path.join(ROOT, "tests", "golden", "bench_loss.json")
+    try:
+        with open(path) as f:
+            ref = json.load(f)[config]["losses"]
+    except (OSError, KeyError, ValueError):
+        return None
+    B = sample[("target_image", 0)].shape[0]
+    trainer._noise = torch.zeros(trainer.num_scales, B, 2, H, W, device=sample[("target_image", 0)].device)
+    with torch.no_grad():
+        was = [m.training for m in (trainer.depth_net, trainer.pose_net)]
+        # training-mode forward without autograd; the BatchNorm running statistics it moves are restored below
+        state = [{k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+                 for m in (trainer.depth_net, trainer.pose_net)]
+        _, losses = trainer.process_batch(sample)
+        got = {k: float(v) for k, v in losses.items()}
+        for m, st in zip((trainer.depth_net, trainer.pose_net), state):
+            m.load_state_dict(st, strict=False)
+        assert was == [True, True]
+    trainer._noise = None
+    trainer._step = 0
+    worst = max(abs(got[k] - ref[k]) / abs(ref[k]) for k in ref)
+    return {"gpu": got["loss"], "oracle": ref["loss"], "worst_rel_err": worst, "tolerance": 2e-4, "ok": worst < 2e-4,
+            "source": "tests/golden/bench_loss.json (oracle networks + loss chain, PyTorch-CPU fp32, tie-break noise 0)"}
 
 
 def pmc_traffic(config, kernel):
@@ -199,12 +276,14 @@ def inference_side(device, with_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=None, help="batch of the CPU baseline (default: the bench batch)")
+    ap.add_argument("--no-stock-caller", action="store_true", help="skip the unchanged-caller (vo/train.py sequence) side measurement")
+    ap.add_argument("--no-loss-check", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[1] side measurement")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-launch HIP-event steps after the timed region (no roofline object in the output)")
@@ -261,15 +340,27 @@ def main():
     pose_stream = trainer.pose_stream
     if args.serialize:
         set_concurrency(False)
+    check = None
+    if rank == 0 and not args.no_loss_check and args.batch is None:
+        check = loss_check(trainer, sample, args.config)
+        if check is not None and not check["ok"]:
+            raise SystemExit("bench.py: first-step loss %.8f differs from the oracle's %.8f (rel %.2e): refusing to time a "
+                             "wrong result" % (check["gpu"], check["oracle"], check["worst_rel_err"]))
     for _ in range(args.warmup):
         gpu_step(trainer, sync, opt, sample)
     barrier()
-    # timed region: K steps, nothing else (no per-launch events)
+    # timed region: K steps, nothing else (no per-launch events; one event record per step on the main stream for the
+    # median, which costs no synchronisation)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         losses = gpu_step(trainer, sync, opt, sample)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    intervals = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = intervals[len(intervals) // 2] if len(intervals) % 2 else 0.5 * (intervals[len(intervals) // 2 - 1] + intervals[len(intervals) // 2])
     # per-kernel durations for the roofline: HIP events around every launch of the library, over further steps
     # of the same loop run on ONE stream -- with DepthNet, PoseNet and the weight gradients overlapping on four
     # streams an event pair measures how long a kernel shared the chip, not how long it needs
@@ -327,18 +418,18 @@ def main():
             roof.update(pmc_traffic(args.config, roof["kernel"]))
         out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": ms_per_step, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": cfg["name"], "per_gpu_batch": batch, "global_batch": batch * world,
                           "num_scales": num_scales, "image": "%dx%d" % (W, H),
-                          "parallelism": "dp%d" % world, "conv_backend": os.environ.get("DVS_CONV_BACKEND", "hip"),
+                          "parallelism": "dp%d" % world,
                           "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient"},
-               "loss": loss_val,
+               "loss": loss_val, "loss_check": check,
                "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
                "conv_kernels": conv_summary,
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, num_scales)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch or batch, num_scales)
         if world == 1 and args.config == "c3" and not args.no_other_configs:
             # BASELINE.json configs[1] (batch 4, single-scale loss) beside the headline workload: same code path,
             # same timing discipline, reported for reference -- `value` above is the batch-12 4-scale step
@@ -349,8 +440,15 @@ def main():
             gradsink.reset_streams()             # the first trainer's streams must not linger (hardware queues are few)
             gc.collect()
             torch.cuda.empty_cache()
+            if not args.no_stock_caller:
+                out["stock_caller"] = time_stock(batch, num_scales, device, rank, min(args.steps, 20), min(args.warmup, 5))
+                torch.cuda.synchronize()
+                gradsink.reset_streams()
+                gc.collect()
+                torch.cuda.empty_cache()
             c2 = CONFIGS["c2"]
             tr2, _, sync2, opt2, sample2 = build_gpu(c2["batch"], c2["num_scales"], device, rank)
+            check2 = loss_check(tr2, sample2, "c2") if not args.no_loss_check else None
             for _ in range(args.warmup):
                 gpu_step(tr2, sync2, opt2, sample2)
             torch.cuda.synchronize()
@@ -361,8 +459,16 @@ def main():
             dt2 = time.perf_counter() - t1
             out["other_configs"] = {"configs[1]": {"workload": c2["name"], "value": 3.0 * c2["batch"] * args.steps / dt2,
                                                    "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
-                                                   "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"]}}
+                                                   "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"],
+                                                   "loss_check": check2}}
             del tr2, sync2, opt2, sample2
+            torch.cuda.synchronize()
+            gradsink.reset_streams()
+            gc.collect()
+            torch.cuda.empty_cache()
+            if not args.no_stock_caller:
+                out["other_configs"]["configs[1]"]["stock_caller"] = time_stock(c2["batch"], c2["num_scales"], device, rank,
+                                                                                 min(args.steps, 20), min(args.warmup, 5))
             torch.cuda.synchronize()
             gradsink.reset_streams()
             gc.collect()

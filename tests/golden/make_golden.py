@@ -61,10 +61,23 @@ def np32(t):
     return t.detach().cpu().numpy()
 
 
-def run_chain(b, h, w, num_scales=4, dump_outputs=True):
+def oob_poses(b):
+    """Motions large enough that a good part of every warp leaves the image: frame -1 samples beyond the right / bottom
+    border, frame +1 beyond the left / top one (border clamp + zero coordinate gradient of F.grid_sample,
+    vo/learner_new.py:165-170)."""
+    rng = np.random.RandomState(23)
+    out = []
+    for sign in (1.0, 1.0):       # frame -1 is built with invert=True, so equal parameters move the two warps apart
+        aa = np.tile(np.array([[[[0.05, -0.08, 0.03]]]]), (b, 1, 1, 1)) * sign + rng.uniform(-0.01, 0.01, size=(b, 1, 1, 3))
+        tt = np.tile(np.array([[[[0.08, 0.05, 0.02]]]]), (b, 1, 1, 1)) * sign + rng.uniform(-0.01, 0.01, size=(b, 1, 1, 3))
+        out += [torch.from_numpy(aa).float(), torch.from_numpy(tt).float()]
+    return out
+
+
+def run_chain(b, h, w, num_scales=4, dump_outputs=True, poses=None):
     sample = synth.parity_sample(b, h, w)
     disps = synth.parity_disps(b, h, w)
-    poses = synth.parity_poses(b)
+    poses = synth.parity_poses(b) if poses is None else poses
     dn, pn = StubDepth(disps), StubPose(poses)
     tr = RL.MonodepthTrainer(dn, pn, config(b, h, w), torch.device("cpu"))
     tr.num_scales = num_scales
@@ -98,6 +111,11 @@ def run_chain(b, h, w, num_scales=4, dump_outputs=True):
     rec["out/T_m1"] = np32(outputs[("cam_T_cam", 0, -1)])
     rec["out/T_p1"] = np32(outputs[("cam_T_cam", 0, 1)])
     rec["meta/num_scales"] = np.array(num_scales)
+    # fraction of scale-0 samples clamped at each border (left, right, top, bottom), per frame
+    for f, nm in ((-1, "m1"), (1, "p1")):
+        g = outputs[("sample", f, 0)].detach()
+        rec["meta/clamped_%s" % nm] = np.array([float((g[..., 0] < -1).float().mean()), float((g[..., 0] > 1).float().mean()),
+                                                float((g[..., 1] < -1).float().mean()), float((g[..., 1] > 1).float().mean())])
     return rec
 
 
@@ -200,6 +218,11 @@ def checksums(rec):
 
 def main():
     torch.set_num_threads(8)
+    if "--oob" in sys.argv:        # only the out-of-image chain fixture (added in round 2; the others are unchanged)
+        rec = run_chain(2, 48, 64, poses=oob_poses(2))
+        print("clamped fractions (left, right, top, bottom): frame -1", rec["meta/clamped_m1"], "frame +1", rec["meta/clamped_p1"])
+        np.savez_compressed(os.path.join(HERE, "chain_b2_48x64_oob.npz"), **rec)
+        return
     np.savez_compressed(os.path.join(HERE, "chain_b2_48x64.npz"), **run_chain(2, 48, 64))
     np.savez_compressed(os.path.join(HERE, "chain_b2_96x128.npz"), **run_chain(2, 96, 128, dump_outputs=False))
     np.savez_compressed(os.path.join(HERE, "chain_b1_48x64_s1.npz"), **run_chain(1, 48, 64, num_scales=1))

@@ -1,0 +1,246 @@
+"""The reference caller's literal sequences on the HIP path (vo/train.py is not importable here -- it pulls in
+tensorboard / the datasets -- so its two step functions are restated line for line):
+
+  * train_mono_step (vo/train.py:173-199): optimizer.zero_grad(set_to_none=True); process_batch; backward;
+    torch.optim.Adam.step(); losses[k].detach().cpu() -- with STOCK torch.optim.Adam over the plain modules, two steps,
+    against oracle networks + oracle chain + torch.optim.Adam on the CPU (losses of both steps, updated weights);
+  * valid_mono_step (vo/train.py:201-217, called under .eval(), :311-331): eval() + no_grad through process_batch
+    (folded-BatchNorm inference path), against the oracle's eval-mode networks;
+  * train -> eval -> FusedAdam step -> eval: the folded-BatchNorm cache must follow the raw-pointer writers
+    (nn_ops.folded_bn generation counter);
+  * eval() WITH autograd (validation loss without no_grad): running statistics, differentiable.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B, H, W = 2, 96, 128
+LR = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _cfg():
+    return {"Train": dict(num_source=1, batch_size=B, img_h=H, img_w=W, smoothness_ratio=0.001, auto_mask=True,
+                          ssim_ratio=0.85, min_depth=0.1, max_depth=10.0, use_compile=False)}
+
+
+def _nets(dev, seed=0):
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    torch.manual_seed(seed)
+    dn, pn = DepthNet(18, pretrained=False), PoseNet(18, pretrained=False, num_input_images=2)
+    sd_d = {k: v.clone() for k, v in dn.state_dict().items()}
+    sd_p = {k: v.clone() for k, v in pn.state_dict().items()}
+    return dn.to(dev), pn.to(dev), sd_d, sd_p
+
+
+def _oracle_losses(sample, sd_d, sd_p, noise, train, update=None):
+    from oracle import loss_chain as OL, networks as ON
+    tgt, left, right = sample[("target_image", 0)], sample[("source_left", 0)], sample[("source_right", 0)]
+    ud, up = ({}, {}) if update is None else update
+    disp = ON.depthnet(tgt, sd_d, train=train, update=ud)
+    aa_l, t_l = ON.posenet(torch.cat([left, tgt], 1), sd_p, train=train, update=up)
+    sd_p2 = dict(sd_p)
+    sd_p2.update({k: v for k, v in up.items()})              # the second PoseNet call sees the first call's running stats
+    aa_r, t_r = ON.posenet(torch.cat([tgt, right], 1), sd_p2, train=train, update=up)
+    _, losses = OL.loss_chain(sample, [disp[("disp", s)] for s in range(4)], (aa_l, t_l, aa_r, t_r), noise)
+    return losses
+
+
+def test_stock_train_mono_step_two_steps(gpu_device):
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    dn, pn, sd_d, sd_p = _nets(gpu_device)
+    dn.train()
+    pn.train()
+    sample = synth.parity_sample(B, H, W)
+    g = torch.Generator().manual_seed(7)
+    noises = [[torch.randn(B, 2, H, W, generator=g) for _ in range(4)] for _ in range(2)]
+    # ---- CPU side: oracle + torch.optim.Adam
+    cd = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd_d.items()}
+    cp = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd_p.items()}
+    copt = torch.optim.Adam([v for v in list(cd.values()) + list(cp.values()) if v.requires_grad], lr=LR)
+    ref_losses = []
+    for it in range(2):
+        copt.zero_grad(set_to_none=True)
+        ud, up = {}, {}
+        losses = _oracle_losses(sample, cd, cp, noises[it], True, (ud, up))
+        losses["loss"].backward()
+        copt.step()
+        with torch.no_grad():
+            for d, u in ((cd, ud), (cp, up)):
+                for k, v in u.items():
+                    d[k] = v.detach().clone()
+        ref_losses.append({k: float(v) for k, v in losses.items()})
+    # ---- GPU side: vo/train.py:114-117 optimiser, :173-199 step, unchanged
+    optimizer = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), lr=LR)
+    learner = MonodepthTrainer(dn, pn, _cfg(), gpu_device)
+    for it in range(2):
+        learner._noise = torch.stack(noises[it]).to(gpu_device)
+        optimizer.zero_grad(set_to_none=True)
+        outputs, losses = learner.process_batch(dict(sample))
+        total_loss = losses["loss"]
+        total_loss.backward()
+        optimizer.step()
+        total_loss = total_loss.detach()
+        for key in losses:
+            losses[key] = losses[key].detach().cpu()
+        assert sorted(losses) == ["loss", "loss/0", "loss/1", "loss/2", "loss/3"]
+        tol = 2e-4 if it == 0 else 1e-3          # step 2 runs on weights that went through one sign-like Adam update
+        for k, v in ref_losses[it].items():
+            assert abs(float(losses[k]) - v) < tol * abs(v), (it, k, float(losses[k]), v)
+    torch.cuda.synchronize()
+    # Adam's first steps move every weight by ~lr * sign(g): elements whose tiny gradient has the other sign differ by
+    # up to 2 * lr * steps; everything else must agree to a small fraction of lr
+    n_bad = n_all = 0
+    for mod, ref in ((dn, cd), (pn, cp)):
+        for k, p in mod.named_parameters():
+            if ".fc." in k:
+                assert torch.equal(p.detach().cpu(), ref[k].detach())      # never touched on either side
+                continue
+            d = (p.detach().cpu() - ref[k].detach()).abs()
+            assert float(d.max()) <= 8.0 * LR, k
+            n_bad += int((d > 0.2 * LR).sum())
+            n_all += d.numel()
+    assert n_bad / n_all < 0.02, n_bad / n_all
+    for mod, ref in ((dn, cd), (pn, cp)):
+        sd = mod.state_dict()
+        for k in ("encoder.encoder.bn1.running_mean", "encoder.encoder.layer4.1.bn2.running_var"):
+            assert rel(sd[k], ref[k]) < 1e-3, k
+        assert int(sd["encoder.encoder.bn1.num_batches_tracked"]) == int(ref["encoder.encoder.bn1.num_batches_tracked"])
+
+
+def test_valid_mono_step_eval_no_grad(gpu_device):
+    """vo/train.py:311-331: depth_net.eval(); pose_net.eval(); valid_mono_step (torch.no_grad) -> process_batch."""
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    dn, pn, sd_d, sd_p = _nets(gpu_device, seed=1)
+    # non-trivial running statistics / affine parameters, same on both sides
+    gen = torch.Generator().manual_seed(5)
+    for sd, mod in ((sd_d, dn), (sd_p, pn)):
+        for k in sd:
+            if k.endswith("running_mean"):
+                sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.2
+            elif k.endswith("running_var"):
+                sd[k] = torch.rand(sd[k].shape, generator=gen) + 0.5
+            elif ".bn" in k and k.endswith(".weight"):
+                sd[k] = torch.rand(sd[k].shape, generator=gen) + 0.5
+        mod.load_state_dict(sd)
+    dn.eval()
+    pn.eval()
+    sample = synth.parity_sample(B, H, W)
+    g = torch.Generator().manual_seed(9)
+    noise = [torch.randn(B, 2, H, W, generator=g) for _ in range(4)]
+    with torch.no_grad():
+        ref = _oracle_losses(sample, sd_d, sd_p, noise, False)
+    learner = MonodepthTrainer(dn, pn, _cfg(), gpu_device)
+    learner._noise = torch.stack(noise).to(gpu_device)
+    with torch.no_grad():
+        outputs, losses = learner.process_batch(dict(sample))
+    total_loss = losses["loss"].detach()
+    assert not total_loss.requires_grad
+    for k in ref:
+        assert abs(float(losses[k]) - float(ref[k])) < 2e-4 * abs(float(ref[k])), k
+    assert outputs[("depth", 0)].shape == (B, 1, H, W)                       # what PlotTool / the commented line reads
+    assert int(dn.state_dict()["encoder.encoder.bn1.num_batches_tracked"]) == 0   # eval: buffers untouched
+
+
+def test_eval_after_fused_adam_step_uses_the_new_weights(gpu_device):
+    """train -> eval -> train step with dp.FusedAdam (raw-pointer weight + running-stat updates) -> eval: the second eval
+    pass must be computed from the updated weights, not from the first pass's cached BatchNorm folds."""
+    from deep_visual_slam_amd import dp, synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from oracle import networks as ON
+    dn, pn, _, _ = _nets(gpu_device, seed=2)
+    flat = dp.FlatParams(dp.trainable_parameters(dn, pn))
+    opt = dp.FusedAdam(flat, lr=1e-2, params=list(dn.parameters()) + list(pn.parameters()))   # large lr: visible change
+    learner = MonodepthTrainer(dn, pn, _cfg(), gpu_device)
+    sample = synth.parity_sample(B, H, W)
+    x = sample[("target_image", 0)]
+    pair = torch.cat([sample[("source_left", 0)], x], 1)
+
+    def eval_pass():
+        dn.eval()
+        pn.eval()
+        with torch.no_grad():
+            d = dn(x.to(gpu_device))[("disp", 0)].clone()
+            aa, t = pn(pair.to(gpu_device))
+        return d, aa.clone(), t.clone()
+
+    def oracle_pass():
+        sd_d = {k: v.detach().cpu().clone() for k, v in dn.state_dict().items()}
+        sd_p = {k: v.detach().cpu().clone() for k, v in pn.state_dict().items()}
+        with torch.no_grad():
+            d = ON.depthnet(x, sd_d, train=False)[("disp", 0)]
+            aa, t = ON.posenet(pair, sd_p, train=False)
+        return d, aa, t
+
+    d0, aa0, t0 = eval_pass()
+    r0 = oracle_pass()
+    assert rel(d0, r0[0]) < 2e-4 and rel(aa0, r0[1]) < 2e-4
+    dn.train()
+    pn.train()
+    opt.zero_grad(set_to_none=True)
+    _, losses = learner.process_batch(dict(sample))
+    losses["loss"].backward()
+    opt.step()
+    d1, aa1, t1 = eval_pass()
+    r1 = oracle_pass()
+    assert rel(r1[0], r0[0]) > 1e-3                       # the step really changed the function
+    assert rel(d1, r1[0]) < 2e-4 and rel(aa1, r1[1]) < 5e-4 and rel(t1, r1[2]) < 5e-4
+    # Adam-layout checkpoint written by the fused optimiser loads into torch.optim.Adam over the same parameters
+    sd = opt.state_dict()
+    ref_opt = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), lr=1e-2)
+    ref_opt.load_state_dict(sd)
+    p0 = next(iter(dn.parameters()))
+    assert float(ref_opt.state[p0]["step"]) == 1.0 and ref_opt.state[p0]["exp_avg"].shape == p0.shape
+    # and the reference scheduler drives it (vo/train.py:120-124)
+    sched = torch.optim.lr_scheduler.PolynomialLR(opt, total_iters=30, power=0.9)
+    sched.step()
+    assert opt.lr < 1e-2
+
+
+def test_eval_mode_with_autograd_is_differentiable_and_uses_running_stats(gpu_device):
+    """Validation loss computed WITHOUT no_grad (the reference allows it): eval-mode BatchNorm = running statistics,
+    gradients flow to the conv weights and to gamma / beta; PoseNet's pair batching must not be required."""
+    from oracle import networks as ON
+    dn, pn, sd_d, sd_p = _nets(gpu_device, seed=3)
+    gen = torch.Generator().manual_seed(6)
+    for sd, mod in ((sd_d, dn), (sd_p, pn)):
+        for k in sd:
+            if k.endswith("running_mean"):
+                sd[k] = torch.randn(sd[k].shape, generator=gen) * 0.2
+            elif k.endswith("running_var"):
+                sd[k] = torch.rand(sd[k].shape, generator=gen) + 0.5
+        mod.load_state_dict(sd)
+    dn.eval()
+    pn.eval()
+    torch.manual_seed(8)
+    x6 = torch.rand(2 * B, 6, H, W)
+    cp = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd_p.items()}
+    aa_r, t_r = ON.posenet(x6, cp, train=False)
+    cot = torch.randn(2 * B, 1, 1, 3)
+    ((aa_r + t_r) * cot).sum().backward()
+    aa, t = pn(x6.to(gpu_device), pairs=2)              # what MonodepthTrainer._predict_poses issues
+    assert aa.requires_grad and rel(aa, aa_r) < 2e-4 and rel(t, t_r) < 2e-4
+    pn.zero_grad(set_to_none=True)
+    ((aa + t) * cot.to(gpu_device)).sum().backward()
+    worst = max((rel(p.grad, cp[n].grad), n) for n, p in pn.named_parameters() if ".fc." not in n)
+    assert worst[0] < 2e-3, worst
+    assert int(pn.state_dict()["encoder.encoder.bn1.num_batches_tracked"]) == 0
+    # DepthNet: all four disparity maps, gradient to a BatchNorm gamma deep in the encoder
+    x3 = torch.rand(B, 3, H, W)
+    cd = {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd_d.items()}
+    ref = ON.depthnet(x3, cd, train=False)
+    out = dn(x3.to(gpu_device))
+    for s in range(4):
+        assert rel(out[("disp", s)], ref[("disp", s)]) < 2e-4
+    sum(ref[("disp", s)].mean() for s in range(4)).backward()
+    sum(out[("disp", s)].mean() for s in range(4)).backward()
+    for n in ("encoder.encoder.layer3.0.bn2.weight", "encoder.encoder.layer2.0.downsample.1.bias", "encoder.encoder.conv1.weight",
+              "decoder.9.conv.conv.weight"):
+        assert rel(dict(dn.named_parameters())[n].grad, cd[n].grad) < 2e-3, n

@@ -57,10 +57,15 @@ def run_chain(dev, sample, disps, poses, noise, ns, materialize=True, auto_mask=
                 d_disp=[d.grad for d in d_disps], d_pose=[p.grad for p in d_poses])
 
 
-@pytest.mark.parametrize("name", ["chain_b2_48x64.npz", "chain_b2_96x128.npz", "chain_b1_48x64_s1.npz"])
+@pytest.mark.parametrize("name", ["chain_b2_48x64.npz", "chain_b2_96x128.npz", "chain_b1_48x64_s1.npz", "chain_b2_48x64_oob.npz"])
 def test_chain_vs_reference_golden(gpu_device, name):
     rec = load_golden(name)
     sample, disps, poses, noise, ns = golden_chain_inputs(rec)
+    if name.endswith("_oob.npz"):
+        # the out-of-image case: >= 10 % of the samples are clamped at each of the four borders (border padding and the
+        # zero coordinate gradient of F.grid_sample, vo/learner_new.py:165-170, through the FUSED chain)
+        cm, cp = rec["meta/clamped_m1"], rec["meta/clamped_p1"]
+        assert cm[0] >= 0.1 and cm[2] >= 0.1 and cp[1] >= 0.1 and cp[3] >= 0.1
     out = run_chain(gpu_device, sample, disps, poses, noise, ns)
     close(out["total"], rec["loss"], 1e-7, 1e-5)
     close(out["T"][0], rec["out/T_m1"], 2e-6, 2e-5)

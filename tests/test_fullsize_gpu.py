@@ -224,6 +224,14 @@ def test_disparity_heads_full_size(gpu_device, case, B):
 
 
 # ------------------------------------------------------------------------------------------------ (b)
+# Gradient yardstick.  The backward pass through ~20 ReLUs / the maxpool is discontinuous: an element whose pre-activation
+# is within rounding of zero takes the other branch in another fp32 implementation, and ONE flipped element moves a
+# gradient tensor by ~1/sqrt(N) of its norm (N = elements of that activation: 1.3e-3 at layer 3), which the training-mode
+# BatchNorms then spread over the whole channel.  tools/grad_truth.py (profiles/r02_grad_truth_*.txt) shows it: against
+# an fp64 run of the oracle, the reference's OWN fp32 CPU arithmetic is off by 3-5e-3 on the encoder tensors, exactly
+# like the HIP path, while tensors before the first flip agree to 1e-6 on both.  So the gradients are judged against
+# the fp64 oracle with the fp32 oracle as the yardstick: the HIP path must be as close to the truth as the reference's
+# arithmetic is -- per tensor within 3x the worst fp32-CPU tensor, in the median within 2x the fp32-CPU median.
 def _fresh_nets(dev, seed=0):
     from deep_visual_slam_amd.depthnet import DepthNet
     from deep_visual_slam_amd.posenet_single import PoseNet
@@ -234,48 +242,69 @@ def _fresh_nets(dev, seed=0):
     return dn.to(dev).train(), pn.to(dev).train(), sd_d, sd_p
 
 
-def _grad_sd(sd):
-    return {k: v.clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd.items()}
+def _grad_sd(sd, dtype=torch.float32):
+    return {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(
+        v.is_floating_point() and ".fc." not in k and "running" not in k) for k, v in sd.items()}
 
 
-def _compare_grads(tag, module, sd_ref, tol, worst_n=4):
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def _judge_grads(tag, module, sd32, sd64, worst_n=3):
     rows = []
     for n, p in module.named_parameters():
-        if ".fc." in n:
-            assert p.grad is None, n
+        g64 = sd64[n].grad
+        if ".fc." in n or g64 is None:
+            assert p.grad is None and sd32[n].grad is None, n        # unused tensors: no gradient on either side
             continue
         assert p.grad is not None, n
-        rows.append((rel(p.grad, sd_ref[n].grad), n))
-    rows.sort(reverse=True)
-    for e, n in rows[:worst_n]:
-        report("%s grad rel-L2 %.2e  %s" % (tag, e, n))
-    report("%s grad rel-L2 median %.2e over %d tensors" % (tag, rows[len(rows) // 2][0], len(rows)))
-    bad = [(e, n) for e, n in rows if not e < tol]
-    assert not bad, bad[:8]
+        rows.append((rel(p.grad, g64), rel(sd32[n].grad, g64), n))
+    worst_cpu = max(r[1] for r in rows)
+    med_gpu, med_cpu = _median([r[0] for r in rows]), _median([r[1] for r in rows])
+    for e, c, n in sorted(rows, reverse=True)[:worst_n]:
+        report("%s grad vs f64: gpu %.2e cpu32 %.2e  %s" % (tag, e, c, n))
+    report("%s grad vs f64 over %d tensors: worst gpu %.2e cpu32 %.2e, median gpu %.2e cpu32 %.2e"
+           % (tag, len(rows), max(r[0] for r in rows), worst_cpu, med_gpu, med_cpu))
+    bad = [(e, n) for e, c, n in rows if not e <= 3.0 * worst_cpu + 1e-5]
+    assert not bad, (bad[:8], worst_cpu)
+    assert med_gpu <= 2.0 * med_cpu + 1e-6, (med_gpu, med_cpu)
     return rows
 
 
+def _oracle_threads():
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+
+
 def test_depthnet_full_size_forward_and_all_weight_gradients(gpu_device):
-    """DepthNet at 480x640, batch 2, training-mode BatchNorm: four disparity maps and all 14.3 M weight gradients
-    against oracle/networks.py (model/depthnet.py:64-90)."""
+    """DepthNet at 480x640, batch 2, training-mode BatchNorm: four disparity maps against the fp32 oracle, all 14.3 M
+    weight gradients against the fp64 oracle with the fp32 oracle as yardstick (model/depthnet.py:64-90)."""
     from oracle import networks as ON
+    _oracle_threads()
     dn, _, sd_d, _ = _fresh_nets(gpu_device)
     torch.manual_seed(3)
     x = torch.rand(2, 3, H, W)
-    sd = _grad_sd(sd_d)
+    sd32, sd64 = _grad_sd(sd_d), _grad_sd(sd_d, torch.float64)
     upd = {}
-    ref = ON.depthnet(x, sd, train=True, update=upd)
+    ref = ON.depthnet(x, sd32, train=True, update=upd)
+    ref64 = ON.depthnet(x.double(), sd64, train=True)
     out = dn(x.to(gpu_device))
     cots = [torch.randn(ref[("disp", s)].shape) / ref[("disp", s)][0].numel() ** 0.5 for s in range(4)]
     for s in range(4):
         e = rel(out[("disp", s)], ref[("disp", s)])
-        report("depthnet 480x640 disp%d rel-L2 %.2e" % (s, e))
-        assert e < 2e-4
+        report("depthnet 480x640 disp%d rel-L2 %.2e (fp32 oracle vs fp64: %.2e)" % (s, e, rel(ref[("disp", s)], ref64[("disp", s)])))
+        assert e < 2e-5                                  # ~40 layers deep, measured 6e-8 .. 7e-7
     sum((ref[("disp", s)] * cots[s]).sum() for s in range(4)).backward()
+    sum((ref64[("disp", s)] * cots[s].double()).sum() for s in range(4)).backward()
     dn.zero_grad(set_to_none=True)
     sum((out[("disp", s)] * cots[s].to(gpu_device)).sum() for s in range(4)).backward()
     torch.cuda.synchronize()
-    _compare_grads("depthnet 480x640 B=2", dn, sd, 2e-3)
+    rows = _judge_grads("depthnet 480x640 B=2", dn, sd32, sd64)
+    # the decoder's own gradients sit in front of every BatchNorm / ReLU of the backward pass: no flips, tight agreement
+    for e, c, n in rows:
+        if n.startswith("decoder."):
+            assert e < 5e-5, (n, e)
     new = dn.state_dict()
     for k in ("encoder.encoder.bn1.running_mean", "encoder.encoder.layer4.1.bn2.running_var",
               "encoder.encoder.layer3.0.downsample.1.running_var"):
@@ -284,40 +313,54 @@ def test_depthnet_full_size_forward_and_all_weight_gradients(gpu_device):
 
 def test_posenet_full_size_forward_and_all_weight_gradients(gpu_device):
     from oracle import networks as ON
+    _oracle_threads()
     _, pn, _, sd_p = _fresh_nets(gpu_device)
     torch.manual_seed(4)
     x = torch.rand(2, 6, H, W)
-    sd = _grad_sd(sd_p)
-    aa_r, t_r = ON.posenet(x, sd, train=True)
+    sd32, sd64 = _grad_sd(sd_p), _grad_sd(sd_p, torch.float64)
+    aa_r, t_r = ON.posenet(x, sd32, train=True)
+    aa_d, t_d = ON.posenet(x.double(), sd64, train=True)
     aa, t = pn(x.to(gpu_device))
     report("posenet 480x640 axisangle rel-L2 %.2e translation %.2e" % (rel(aa, aa_r), rel(t, t_r)))
-    assert rel(aa, aa_r) < 2e-4 and rel(t, t_r) < 2e-4
+    assert rel(aa, aa_r) < 2e-5 and rel(t, t_r) < 2e-5
     cot = torch.randn(2, 1, 1, 3)
     ((aa_r + t_r) * cot).sum().backward()
+    ((aa_d + t_d) * cot.double()).sum().backward()
     pn.zero_grad(set_to_none=True)
     ((aa + t) * cot.to(gpu_device)).sum().backward()
     torch.cuda.synchronize()
-    _compare_grads("posenet 480x640 B=2", pn, sd, 2e-3)
+    rows = _judge_grads("posenet 480x640 B=2", pn, sd32, sd64)
+    for e, c, n in rows:
+        if n.startswith("net."):                         # pose decoder: in front of the encoder's BatchNorms
+            assert e < 5e-5, (n, e)
 
 
 # ------------------------------------------------------------------------------------------------ (c)
-def _full_step(gpu_device, B, num_scales, tol_grad):
+def _oracle_step(sample, sd_d, sd_p, noise, num_scales, dtype):
+    from oracle import loss_chain as OL, networks as ON
+    cast = lambda t: t.to(dtype) if t.is_floating_point() else t
+    smp = {k: cast(v) for k, v in sample.items()}
+    sdd, sdp = _grad_sd(sd_d, dtype), _grad_sd(sd_p, dtype)
+    tgt, left, right = smp[("target_image", 0)], smp[("source_left", 0)], smp[("source_right", 0)]
+    disp = ON.depthnet(tgt, sdd, train=True)
+    aa_l, t_l = ON.posenet(torch.cat([left, tgt], 1), sdp, train=True)
+    aa_r, t_r = ON.posenet(torch.cat([tgt, right], 1), sdp, train=True)
+    _, losses = OL.loss_chain(smp, [disp[("disp", s)] for s in range(num_scales)], (aa_l, t_l, aa_r, t_r),
+                              [cast(n) for n in noise], num_scales=num_scales)
+    losses["loss"].backward()
+    return sdd, sdp, disp, (aa_l, t_l, aa_r, t_r), {k: float(v) for k, v in losses.items()}
+
+
+def _full_step(gpu_device, B, num_scales):
     from deep_visual_slam_amd import gradsink, synth
     from deep_visual_slam_amd.learner_new import MonodepthTrainer
-    from oracle import loss_chain as OL, networks as ON
+    _oracle_threads()
     dn, pn, sd_d, sd_p = _fresh_nets(gpu_device)
     sample = synth.parity_sample(B, H, W)
     g = torch.Generator().manual_seed(7)
     noise = [torch.randn(B, 2, H, W, generator=g) for _ in range(num_scales)]
-    tgt, left, right = sample[("target_image", 0)], sample[("source_left", 0)], sample[("source_right", 0)]
-    sdd, sdp = _grad_sd(sd_d), _grad_sd(sd_p)
-    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
-    disp = ON.depthnet(tgt, sdd, train=True)
-    aa_l, t_l = ON.posenet(torch.cat([left, tgt], 1), sdp, train=True)
-    aa_r, t_r = ON.posenet(torch.cat([tgt, right], 1), sdp, train=True)
-    _, ref = OL.loss_chain(sample, [disp[("disp", s)] for s in range(num_scales)], (aa_l, t_l, aa_r, t_r), noise,
-                           num_scales=num_scales)
-    ref["loss"].backward()
+    d32, p32, disp, (aa_l, t_l, aa_r, t_r), ref = _oracle_step(sample, sd_d, sd_p, noise, num_scales, torch.float32)
+    d64, p64, _, _, ref64 = _oracle_step(sample, sd_d, sd_p, noise, num_scales, torch.float64)
     cfg = {"Train": dict(num_source=1, batch_size=B, img_h=H, img_w=W, smoothness_ratio=0.001, auto_mask=True,
                          ssim_ratio=0.85, min_depth=0.1, max_depth=10.0, use_compile=False)}
     tr = MonodepthTrainer(dn, pn, cfg, gpu_device)
@@ -327,30 +370,31 @@ def _full_step(gpu_device, B, num_scales, tol_grad):
     keys = ["loss"] + ["loss/%d" % s for s in range(num_scales)]
     assert sorted(losses) == sorted(keys)
     for k in keys:
-        e = abs(float(losses[k]) - float(ref[k])) / abs(float(ref[k]))
-        report("step B=%d S=%d %-7s gpu %.8f oracle %.8f rel %.2e" % (B, num_scales, k, float(losses[k]), float(ref[k]), e))
+        e = abs(float(losses[k]) - ref[k]) / abs(ref[k])
+        report("step B=%d S=%d %-7s gpu %.8f oracle %.8f rel %.2e (fp32 oracle vs fp64: %.2e)"
+               % (B, num_scales, k, float(losses[k]), ref[k], e, abs(ref[k] - ref64[k]) / abs(ref64[k])))
         assert e < 2e-4, k
     for s in range(num_scales):
-        assert rel(outputs[("disp", s)], disp[("disp", s)]) < 2e-4
+        assert rel(outputs[("disp", s)], disp[("disp", s)]) < 2e-5
     for f, (aa, t) in ((-1, (aa_l, t_l)), (1, (aa_r, t_r))):
-        assert rel(outputs[("axisangle", 0, f)], aa) < 5e-4 and rel(outputs[("translation", 0, f)], t) < 5e-4
+        assert rel(outputs[("axisangle", 0, f)], aa) < 2e-5 and rel(outputs[("translation", 0, f)], t) < 2e-5
     dn.zero_grad(set_to_none=True)
     pn.zero_grad(set_to_none=True)
     losses["loss"].backward()
     gradsink.join()
     torch.cuda.synchronize()
     tag = "step B=%d S=%d" % (B, num_scales)
-    _compare_grads(tag + " depth", dn, sdd, tol_grad)
-    _compare_grads(tag + " pose ", pn, sdp, tol_grad)
+    _judge_grads(tag + " depth", dn, d32, d64)
+    _judge_grads(tag + " pose ", pn, p32, p64)
     # lazily materialised outputs at full size keep the reference's schema
     assert outputs[("color", -1, 0)].shape == (B, 3, H, W) and outputs[("sample", 1, 0)].shape == (B, H, W, 2)
 
 
 def test_full_step_config1_batch4_single_scale(gpu_device):
     """BASELINE.json configs[1]: 3-frame 640x480 snippet, batch 4, single-scale loss (trainer.num_scales = 1)."""
-    _full_step(gpu_device, 4, 1, 5e-3)
+    _full_step(gpu_device, 4, 1)
 
 
 def test_full_step_config2_batch12_four_scales(gpu_device):
     """BASELINE.json configs[2] (= configs[3] per GPU): full 4-scale photometric + smoothness loss, batch 12."""
-    _full_step(gpu_device, 12, 4, 5e-3)
+    _full_step(gpu_device, 12, 4)

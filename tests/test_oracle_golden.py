@@ -113,7 +113,7 @@ def test_smoothness(ops):
     close(d.grad, ops["smooth/d_disp"], atol=1e-7, rtol=1e-3)
 
 
-@pytest.mark.parametrize("name", ["chain_b2_48x64.npz", "chain_b2_96x128.npz", "chain_b1_48x64_s1.npz"])
+@pytest.mark.parametrize("name", ["chain_b2_48x64.npz", "chain_b2_96x128.npz", "chain_b1_48x64_s1.npz", "chain_b2_48x64_oob.npz"])
 def test_whole_chain(name):
     rec = load_golden(name)
     sample, disps, poses, noise, ns = golden_chain_inputs(rec)

@@ -83,6 +83,21 @@ def main():
         return outs, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
 
     og, g1 = gpu_run()
+    # ReLU branch flips: elements of the encoder's five feature maps (stem, layer1..4 outputs) whose sign pattern (> 0)
+    # differs from the fp64 run -- the discontinuities of the backward pass
+    with torch.no_grad():
+        pre = "encoder.encoder"
+        s64n = {k: v.detach() for k, v in s64.items()}
+        s32n = {k: v.detach() for k, v in s32.items()}
+        xin = x if args.pairs == 1 or args.net == "depth" else x[:args.B]
+        f64 = ON.resnet_encoder(xin.double(), s64n, pre, train)
+        f32 = ON.resnet_encoder(xin, s32n, pre, train)
+        fg = [f.detach().cpu() for f in net.encoder.features]
+        for i, (a, b, c) in enumerate(zip(fg, f32, f64)):
+            a = a[:c.shape[0]]
+            near = int((c.abs() < 1e-6 * c.abs().max()).sum()) - int((c == 0).sum())
+            print("feature %d: %9d elements, ReLU-sign flips vs f64: gpu %d, cpu32 %d; |f64| within 1e-6 of max but nonzero: %d"
+                  % (i, c.numel(), int(((a > 0) != (c > 0)).sum()), int(((b > 0) != (c > 0)).sum()), near))
     # restore the buffers the first run updated (running statistics) so that the second run sees the same state
     net.load_state_dict({k: v.to(dev) for k, v in sd.items()})
     _, g2 = gpu_run()
