@@ -108,17 +108,25 @@ struct Warp {
     bool in_x1, in_y1;
 };
 
-// BackprojectDepth -> Project3D -> grid_sample coordinate, with the reference's operation order.
-__device__ __forceinline__ void warp_geom(const CamMats& m, const Geo& g, int X, int Y, float disp_up, Warp& w) {
-    w.depth = frcp(g.min_disp + g.disp_range * disp_up);
+// Pixel ray inv_K[:3,:3].[X,Y,1] (BackprojectDepth's pix_coords product): scale- and frame-invariant.
+__device__ __forceinline__ void pixel_ray(const float* __restrict__ iK, int X, int Y, float& c0, float& c1, float& c2) {
     float fx = (float)X, fy = (float)Y;
-    w.c0 = fmaf(m.iK[1], fy, m.iK[0] * fx) + m.iK[2];
-    w.c1 = fmaf(m.iK[4], fy, m.iK[3] * fx) + m.iK[5];
-    w.c2 = fmaf(m.iK[7], fy, m.iK[6] * fx) + m.iK[8];
-    float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
-    float p0 = fmaf(m.P[2], Z3, fmaf(m.P[1], Y3, m.P[0] * X3)) + m.P[3];
-    float p1 = fmaf(m.P[6], Z3, fmaf(m.P[5], Y3, m.P[4] * X3)) + m.P[7];
-    float p2 = fmaf(m.P[10], Z3, fmaf(m.P[9], Y3, m.P[8] * X3)) + m.P[11];
+    c0 = fmaf(iK[1], fy, iK[0] * fx) + iK[2];
+    c1 = fmaf(iK[4], fy, iK[3] * fx) + iK[5];
+    c2 = fmaf(iK[7], fy, iK[6] * fx) + iK[8];
+}
+
+// depth * ray -> Project3D -> grid_sample coordinate, with the reference's operation order.  P = (K @ T)[:3,:].
+__device__ __forceinline__ void warp_project(const float* __restrict__ P, const Geo& g, float depth, float c0, float c1,
+                                             float c2, Warp& w) {
+    w.depth = depth;
+    w.c0 = c0;
+    w.c1 = c1;
+    w.c2 = c2;
+    float X3 = depth * c0, Y3 = depth * c1, Z3 = depth * c2;
+    float p0 = fmaf(P[2], Z3, fmaf(P[1], Y3, P[0] * X3)) + P[3];
+    float p1 = fmaf(P[6], Z3, fmaf(P[5], Y3, P[4] * X3)) + P[7];
+    float p2 = fmaf(P[10], Z3, fmaf(P[9], Y3, P[8] * X3)) + P[11];
     w.rden = frcp(p2 + 1e-7f);
     w.u = p0 * w.rden;
     w.v = p1 * w.rden;
@@ -137,6 +145,13 @@ __device__ __forceinline__ void warp_geom(const CamMats& m, const Geo& g, int X,
     w.ty = iy - y0f;
     w.in_x1 = (w.x0 + 1) <= g.W - 1;
     w.in_y1 = (w.y0 + 1) <= g.H - 1;
+}
+
+// BackprojectDepth -> Project3D -> grid_sample coordinate for one pixel and one frame.
+__device__ __forceinline__ void warp_geom(const CamMats& m, const Geo& g, int X, int Y, float disp_up, Warp& w) {
+    float c0, c1, c2;
+    pixel_ray(m.iK, X, Y, c0, c1, c2);
+    warp_project(m.P, g, frcp(g.min_disp + g.disp_range * disp_up), c0, c1, c2, w);
 }
 
 // Gather the 4 neighbours of one channel plane (out-of-range upper neighbours contribute 0).
@@ -215,6 +230,69 @@ __device__ __forceinline__ void reproj_strip(const float* __restrict__ sX, const
         out[k] = ssim_ratio * (ssim_sum[k] * (1.f / 3.f)) + (1.f - ssim_ratio) * (l1_sum[k] * (1.f / 3.f));
 }
 
+// The same for TWO predictions of one target at once (the two source frames of a scale, or the two identity candidates):
+// the target-side row sums (y, y^2) and statistics (mu_y, sigma_y) are formed once and shared.
+template <int LD, int PLANE>
+__device__ __forceinline__ void reproj_pair(const float* __restrict__ sXa, const float* __restrict__ sXb,
+                                            const float* __restrict__ sT, int ly0, int lx, float ssim_ratio, float outa[PX],
+                                            float outb[PX]) {
+    float ssa[PX] = {0.f, 0.f, 0.f, 0.f}, ssb[PX] = {0.f, 0.f, 0.f, 0.f};
+    float l1a[PX] = {0.f, 0.f, 0.f, 0.f}, l1b[PX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        const int o = c * PLANE + ly0 * LD + lx;
+        const float* xa = sXa + o;
+        const float* xb = sXb + o;
+        const float* y = sT + o;
+        float ry[PX + 2], ryy[PX + 2], ax[PX + 2], axx[PX + 2], axy[PX + 2], bx[PX + 2], bxx[PX + 2], bxy[PX + 2];
+#pragma unroll
+        for (int j = 0; j < PX + 2; ++j) {
+            const float y0 = y[j * LD], y1 = y[j * LD + 1], y2 = y[j * LD + 2];
+            const float a0 = xa[j * LD], a1 = xa[j * LD + 1], a2 = xa[j * LD + 2];
+            const float b0 = xb[j * LD], b1 = xb[j * LD + 1], b2 = xb[j * LD + 2];
+            ry[j] = y0 + y1 + y2;
+            ryy[j] = fmaf(y2, y2, fmaf(y1, y1, y0 * y0));
+            ax[j] = a0 + a1 + a2;
+            axx[j] = fmaf(a2, a2, fmaf(a1, a1, a0 * a0));
+            axy[j] = fmaf(a2, y2, fmaf(a1, y1, a0 * y0));
+            bx[j] = b0 + b1 + b2;
+            bxx[j] = fmaf(b2, b2, fmaf(b1, b1, b0 * b0));
+            bxy[j] = fmaf(b2, y2, fmaf(b1, y1, b0 * y0));
+            if (j >= 1 && j <= PX) {
+                l1a[j - 1] += fabsf(y1 - a1);
+                l1b[j - 1] += fabsf(y1 - b1);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const float muy = (ry[k] + ry[k + 1] + ry[k + 2]) * K9;
+            const float sigy = (ryy[k] + ryy[k + 1] + ryy[k + 2]) * K9 - muy * muy;
+            const float my2 = fmaf(muy, muy, C1), sy2 = sigy + C2;
+            {
+                const float mux = (ax[k] + ax[k + 1] + ax[k + 2]) * K9;
+                const float sigx = (axx[k] + axx[k + 1] + axx[k + 2]) * K9 - mux * mux;
+                const float sigxy = (axy[k] + axy[k + 1] + axy[k + 2]) * K9 - mux * muy;
+                const float n = (2.f * mux * muy + C1) * (2.f * sigxy + C2);
+                const float d = fmaf(mux, mux, my2) * (sigx + sy2);
+                ssa[k] += fminf(fmaxf((1.f - n * frcp(d)) * 0.5f, 0.f), 1.f);
+            }
+            {
+                const float mux = (bx[k] + bx[k + 1] + bx[k + 2]) * K9;
+                const float sigx = (bxx[k] + bxx[k + 1] + bxx[k + 2]) * K9 - mux * mux;
+                const float sigxy = (bxy[k] + bxy[k + 1] + bxy[k + 2]) * K9 - mux * muy;
+                const float n = (2.f * mux * muy + C1) * (2.f * sigxy + C2);
+                const float d = fmaf(mux, mux, my2) * (sigx + sy2);
+                ssb[k] += fminf(fmaxf((1.f - n * frcp(d)) * 0.5f, 0.f), 1.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+        outa[k] = ssim_ratio * (ssa[k] * (1.f / 3.f)) + (1.f - ssim_ratio) * (l1a[k] * (1.f / 3.f));
+        outb[k] = ssim_ratio * (ssb[k] * (1.f / 3.f)) + (1.f - ssim_ratio) * (l1b[k] * (1.f / 3.f));
+    }
+}
+
 // ------------------------------------------------------------------------------ counter-based noise
 // Philox4x32-10 (Salmon et al.); stands in for the reference's torch.randn tie-break noise
 // (learner_new.py:226-229) when the caller does not inject a noise tensor.
@@ -264,10 +342,42 @@ __device__ __forceinline__ float edge_weight(const float* __restrict__ sT, int o
 }
 
 // ------------------------------------------------------------------------------------- forward
+// Per-image camera table behind the [B][S][4] statistics of the `stats` workspace: CAM_STRIDE floats per image =
+// inv_K[:3,:3] (9, padded to 12), (K @ T_-1)[:3,:] (12), (K @ T_+1)[:3,:] (12).  Written by one tiny kernel per forward
+// call; the main kernels read it with scalar loads (uniform per workgroup) instead of re-deriving K @ T on the vector
+// ALUs for every scale and frame, and the backward finds it where the forward left it.
+constexpr int CAM_STRIDE = 36;
+__device__ __forceinline__ const float* cam_table(const ChainParams& p, int b) {
+    return p.io.stats + (size_t)p.cfg.B * p.cfg.num_scales * 4 + (size_t)b * CAM_STRIDE;
+}
+
+__global__ void chain_cam_kernel(ChainParams p) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* out = p.io.stats + (size_t)p.cfg.B * p.cfg.num_scales * 4 + (size_t)b * CAM_STRIDE;
+    if (t < 12) {
+        const float* iK = p.io.inv_K + b * 16;
+        out[t] = (t < 9) ? iK[(t / 3) * 4 + (t % 3)] : 0.f;
+    } else if (t < 36) {
+        const int f = (t - 12) / 12, e = (t - 12) % 12, i = e / 4, j = e % 4;
+        const float* K = p.io.K + b * 16;
+        const float* T = p.io.T[f] + b * 16;
+        float acc = K[i * 4 + 0] * T[0 * 4 + j];
+        acc = fmaf(K[i * 4 + 1], T[1 * 4 + j], acc);
+        acc = fmaf(K[i * 4 + 2], T[2 * 4 + j], acc);
+        acc = fmaf(K[i * 4 + 3], T[3 * 4 + j], acc);
+        out[t] = acc;
+    }
+}
+
+// Halo positions sH[i] of the (TH+2) x (TW+2) tile, packed as gx | gy << 16 | interior << 31 (gx, gy = reflected image
+// coordinates; interior = a pixel of the tile proper that lies inside the image).  The division by the tile width and the
+// two reflections are done once per workgroup; every staging loop (S scales x 2 frames) reads one LDS word instead.
+
 __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p) {
     __shared__ float sT[3 * FH * FW];
-    __shared__ float sX[3 * FH * FW];
+    __shared__ float sX[2][3 * FH * FW];       // the two predictions compared with the target tile (both frames at once)
     __shared__ float sD[FH * FW];
+    __shared__ uint32_t sH[FH * FW];            // halo positions, see below
     __shared__ float sRed[NT / 64][NPART];
 
     const dvs_chain_cfg& c = p.cfg;
@@ -279,43 +389,37 @@ __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p)
     const int X = X0 + tx, Yb = Y0 + PX * ty;      // my strip: column X, rows Yb .. Yb+3
 
     const float* tgt = p.io.target + (size_t)b * 3 * HW;
+    const float* src0 = p.io.source[0] + (size_t)b * 3 * HW;
+    const float* src1 = p.io.source[1] + (size_t)b * 3 * HW;
     for (int i = tid; i < PL; i += NT) {
-        int hy = i / FW, hx = i - hy * FW;
-        int gx = reflect_idx(X0 - 1 + hx, W), gy = reflect_idx(Y0 - 1 + hy, H);
+        const int hy = i / FW, hx = i - hy * FW;
+        const int px = X0 - 1 + hx, py = Y0 - 1 + hy;
+        const int gx = reflect_idx(px, W), gy = reflect_idx(py, H);
+        const bool interior = hx >= 1 && hx <= TW && hy >= 1 && hy <= TH && px < W && py < H;
+        sH[i] = (uint32_t)gx | ((uint32_t)gy << 16) | (interior ? 0x80000000u : 0u);
+        const int o = gy * W + gx;
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) sT[ch * PL + i] = tgt[ch * HW + gy * W + gx];
+        for (int ch = 0; ch < 3; ++ch) sT[ch * PL + i] = tgt[ch * HW + o];
+        if (c.auto_mask) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                sX[0][ch * PL + i] = src0[ch * HW + o];
+                sX[1][ch * PL + i] = src1[ch * HW + o];
+            }
+        }
     }
-
+    __syncthreads();
     float ident[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (c.auto_mask) {
-#pragma unroll 1
-        for (int f = 0; f < 2; ++f) {
-            const float* src = p.io.source[f] + (size_t)b * 3 * HW;
-            for (int i = tid; i < PL; i += NT) {
-                int hy = i / FW, hx = i - hy * FW;
-                int gx = reflect_idx(X0 - 1 + hx, W), gy = reflect_idx(Y0 - 1 + hy, H);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) sX[ch * PL + i] = src[ch * HW + gy * W + gx];
-            }
-            __syncthreads();
-            {
-                float tmp[PX];
-                reproj_strip<FW, PL>(sX, sT, PX * ty, tx, c.ssim_ratio, tmp);
-#pragma unroll
-                for (int k = 0; k < PX; ++k) {   // static indices only: a runtime-indexed array would live in scratch
-                    ident[0][k] = (f == 0) ? tmp[k] : ident[0][k];
-                    ident[1][k] = (f == 1) ? tmp[k] : ident[1][k];
-                }
-            }
-            __syncthreads();
-        }
-    } else {
+        reproj_pair<FW, PL>(sX[0], sX[1], sT, PX * ty, tx, c.ssim_ratio, ident[0], ident[1]);
         __syncthreads();
     }
 
     uint32_t selbits[PX] = {0, 0, 0, 0};
+    uint32_t rnd[PX][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};      // second half of a Philox block, kept for the odd scale
     const int wave = tid >> 6, lane = tid & 63;
     if (tid < NPART) sRed[0][tid] = sRed[1][tid] = sRed[2][tid] = sRed[3][tid] = 0.f;
+    const float* cam = cam_table(p, b);        // uniform: scalar loads
 
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
@@ -323,62 +427,61 @@ __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p)
         const bool same_res = (hs == H && ws == W);
         const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
         const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
-        float rp[2][PX] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float rp[2][PX];
         float a_min = 0.f, a_disp = 0.f, a_gx = 0.f, a_gy = 0.f;   // this scale's partial sums
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {
-            CamMats m;
-            load_cam(p, b, f, m);
-            const float* src = p.io.source[f] + (size_t)b * 3 * HW;
+            const float* P = cam + 12 + 12 * f;
+            const float* src = f ? src1 : src0;
+            float* sXf = sX[f];
             float* o_color = p.io.color[s][f];
             float* o_grid = p.io.grid[s][f];
             float* o_dup = (f == 0) ? p.io.disp_up[s] : nullptr;
             float* o_depth = (f == 0) ? p.io.depth[s] : nullptr;
             const bool materialize = o_color || o_grid || o_dup || o_depth;
             for (int i = tid; i < PL; i += NT) {
-                int hy = i / FW, hx = i - hy * FW;
-                int px = X0 - 1 + hx, py = Y0 - 1 + hy;
-                int gx = reflect_idx(px, W), gy = reflect_idx(py, H);
-                float du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
-                if (f == 0) sD[i] = du;
+                const uint32_t h = sH[i];
+                const int gx = (int)(h & 0xffffu), gy = (int)((h >> 16) & 0x7fffu);
+                // the upsampled disparity is formed for frame -1 and re-read from the LDS tile for frame +1
+                float du;
+                if (f == 0) {
+                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
+                    sD[i] = du;
+                } else {
+                    du = sD[i];
+                }
+                const float depth = frcp(geo.min_disp + geo.disp_range * du);
+                float c0, c1, c2;
+                pixel_ray(cam, gx, gy, c0, c1, c2);
                 Warp w;
-                warp_geom(m, geo, gx, gy, du, w);
+                warp_project(P, geo, depth, c0, c1, c2, w);
                 float col[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     float nw, ne, sw, se;
                     gather4(src + ch * HW, W, w, nw, ne, sw, se);
                     col[ch] = bilerp(w, nw, ne, sw, se);
-                    sX[ch * PL + i] = col[ch];
+                    sXf[ch * PL + i] = col[ch];
                 }
                 // optional materialisation of the reference's `outputs` tensors (interior pixels only)
-                if (materialize && hx >= 1 && hx <= TW && hy >= 1 && hy <= TH && px < W && py < H) {
-                    size_t o = (size_t)b * HW + (size_t)py * W + px;
+                if (materialize && (h >> 31)) {
+                    const size_t o = (size_t)b * HW + (size_t)gy * W + gx;        // interior: (gx, gy) is the pixel itself
                     if (o_color) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch)
-                            o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)py * W + px] = col[ch];
+                            o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)gy * W + gx] = col[ch];
                     }
                     if (o_grid) {
                         o_grid[o * 2 + 0] = w.gx;
                         o_grid[o * 2 + 1] = w.gy;
                     }
                     if (o_dup) o_dup[o] = du;
-                    if (o_depth) o_depth[o] = w.depth;
+                    if (o_depth) o_depth[o] = depth;
                 }
             }
-            __syncthreads();
-            {
-                float tmp[PX];
-                reproj_strip<FW, PL>(sX, sT, PX * ty, tx, c.ssim_ratio, tmp);
-#pragma unroll
-                for (int k = 0; k < PX; ++k) {
-                    rp[0][k] = (f == 0) ? tmp[k] : rp[0][k];
-                    rp[1][k] = (f == 1) ? tmp[k] : rp[1][k];
-                }
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        reproj_pair<FW, PL>(sX[0], sX[1], sT, PX * ty, tx, c.ssim_ratio, rp[0], rp[1]);
 
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
@@ -393,12 +496,15 @@ __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p)
                     const float* nz = p.io.noise + ((size_t)s * c.B + b) * 2 * HW + (size_t)Y * W + X;
                     n0 = nz[0];
                     n1 = nz[HW];
+                } else if (s & 1) {
+                    box_muller(rnd[k][0], rnd[k][1], n0, n1);            // second half of the block drawn at scale s - 1
                 } else {
                     uint32_t r[4];
                     philox4x32((uint32_t)(Y * W + X), (uint32_t)b, (uint32_t)(s >> 1), 0u,
                                (uint32_t)p.io.seed, (uint32_t)(p.io.seed >> 32), r);
-                    if (s & 1) box_muller(r[2], r[3], n0, n1);
-                    else box_muller(r[0], r[1], n0, n1);
+                    box_muller(r[0], r[1], n0, n1);
+                    rnd[k][0] = r[2];
+                    rnd[k][1] = r[3];
                 }
                 float i0 = ident[0][k] + n0 * 0.00001f, i1 = ident[1][k] + n1 * 0.00001f;
                 best = i0;
@@ -498,6 +604,7 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
     __shared__ float sD[BH * BW];
     __shared__ float sF[3 * FH * FW];     // SSIM derivative fields of one channel; reused as sAcc
     __shared__ uint8_t sSel[FH * FW];
+    __shared__ uint32_t sH[BH * BW];      // halo positions gx | gy << 16 of the 2-px-halo tile (see the forward kernel)
     __shared__ float sRed[NT / 64][NDP];
     float* sAcc = sF;
 
@@ -515,9 +622,11 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
     for (int i = tid; i < PLB; i += NT) {
         int hy = i / BW, hx = i - hy * BW;
         int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
+        sH[i] = (uint32_t)gx | ((uint32_t)gy << 16);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) sT[ch * PLB + i] = tgt[ch * HW + gy * W + gx];
     }
+    const float* cam = cam_table(p, b);        // uniform: scalar loads (written by the forward call)
     for (int i = tid; i < PLF; i += NT) {
         int hy = i / FW, hx = i - hy * FW;
         int px = X0 - 1 + hx, py = Y0 - 1 + hy;
@@ -554,17 +663,23 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
 
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {
-            CamMats m;
-            load_cam(p, b, f, m);
+            const float* P = cam + 12 + 12 * f;
             const float* src = p.io.source[f] + (size_t)b * 3 * HW;
             const uint32_t want = 2u + (uint32_t)f;
             for (int i = tid; i < PLB; i += NT) {
-                int hy = i / BW, hx = i - hy * BW;
-                int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
-                float du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
-                if (f == 0) sD[i] = du;
+                const uint32_t h = sH[i];
+                const int gx = (int)(h & 0xffffu), gy = (int)(h >> 16);
+                float du;
+                if (f == 0) {
+                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
+                    sD[i] = du;
+                } else {
+                    du = sD[i];
+                }
+                float c0, c1, c2;
+                pixel_ray(cam, gx, gy, c0, c1, c2);
                 Warp w;
-                warp_geom(m, geo, gx, gy, du, w);
+                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     float nw, ne, sw, se;
@@ -648,8 +763,10 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
                 int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
                 float du = sD[(PX * ty + k + 2) * BW + tx + 2];
+                float c0, c1, c2;
+                pixel_ray(cam, X, Y, c0, c1, c2);
                 Warp w;
-                warp_geom(m, geo, X, Y, du, w);
+                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);
                 float gix = 0.f, giy = 0.f;
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -667,9 +784,9 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
                 dP[0] += dp0 * X3; dP[1] += dp0 * Y3; dP[2] += dp0 * Z3; dP[3] += dp0;
                 dP[4] += dp1 * X3; dP[5] += dp1 * Y3; dP[6] += dp1 * Z3; dP[7] += dp1;
                 dP[8] += dp2 * X3; dP[9] += dp2 * Y3; dP[10] += dp2 * Z3; dP[11] += dp2;
-                float dc0 = m.P[0] * dp0 + m.P[4] * dp1 + m.P[8] * dp2;
-                float dc1 = m.P[1] * dp0 + m.P[5] * dp1 + m.P[9] * dp2;
-                float dc2 = m.P[2] * dp0 + m.P[6] * dp1 + m.P[10] * dp2;
+                float dc0 = P[0] * dp0 + P[4] * dp1 + P[8] * dp2;
+                float dc1 = P[1] * dp0 + P[5] * dp1 + P[9] * dp2;
+                float dc2 = P[2] * dp0 + P[6] * dp1 + P[10] * dp2;
                 float d_depth = dc0 * w.c0 + dc1 * w.c1 + dc2 * w.c2;
                 gd[k] += d_depth * (-w.depth * w.depth * geo.disp_range);
             }
@@ -814,7 +931,7 @@ int dvs_chain_workspace(const dvs_chain_cfg* cfg, size_t* partials_bytes, size_t
     size_t ntiles = (size_t)((cfg->W + TW - 1) / TW) * ((cfg->H + TH - 1) / TH);
     if (partials_bytes) *partials_bytes = (size_t)cfg->B * ntiles * NPART * sizeof(float);
     if (sel_bytes) *sel_bytes = (size_t)cfg->B * cfg->H * cfg->W;
-    if (stats_bytes) *stats_bytes = (size_t)cfg->B * cfg->num_scales * 4 * sizeof(float);
+    if (stats_bytes) *stats_bytes = ((size_t)cfg->B * cfg->num_scales * 4 + (size_t)cfg->B * CAM_STRIDE) * sizeof(float);
     if (bwd_partials_bytes) *bwd_partials_bytes = (size_t)cfg->B * ntiles * cfg->num_scales * 2 * NDP * sizeof(float);
     return DVS_OK;
 }
@@ -829,6 +946,7 @@ int dvs_chain_fwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, void* st
     for (int s = 0; s < cfg->num_scales; ++s) DVS_REQUIRE(io->disp[s], "dvs_chain_fwd: null disp[%d]", s);
     ChainParams p = make_params(cfg, io);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(chain_cam_kernel, dim3(cfg->B), dim3(64), 0, st, p);
     {
         dvs::ProfScope prof(dvs::SLOT_CHAIN_FWD, st);
         hipLaunchKernelGGL(chain_fwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p);

@@ -92,7 +92,7 @@ class _LossChain(torch.autograd.Function):
         nb = chain_workspace_bytes(cfg)
         partials = torch.empty(nb[0] // 4, device=dev, dtype=torch.float32)
         sel = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
-        stats = torch.empty(B, S, 4, device=dev, dtype=torch.float32)
+        stats = torch.empty(nb[2] // 4, device=dev, dtype=torch.float32)   # [B,S,4] sums + the per-image camera table
         losses = torch.empty(S, device=dev, dtype=torch.float32)
         io = ChainFwdIO()
         io.target = ptr(target)

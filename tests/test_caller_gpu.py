@@ -229,8 +229,11 @@ def test_eval_mode_with_autograd_is_differentiable_and_uses_running_stats(gpu_de
     assert aa.requires_grad and rel(aa, aa_r) < 2e-4 and rel(t, t_r) < 2e-4
     pn.zero_grad(set_to_none=True)
     ((aa + t) * cot.to(gpu_device)).sum().backward()
+    # eval mode: no batch coupling, but one ReLU branch flip still moves a tensor by ~1/sqrt(elements of that map)
+    # (tools/grad_truth.py --eval-bn: fp32 CPU vs fp64 shows the same steps); smallest map here: 4 x 3 x 4 x 256
+    flip = 1.0 / (2 * B * 3 * 4 * 256) ** 0.5
     worst = max((rel(p.grad, cp[n].grad), n) for n, p in pn.named_parameters() if ".fc." not in n)
-    assert worst[0] < 2e-3, worst
+    assert worst[0] < 2e-3 + 2 * flip, worst
     assert int(pn.state_dict()["encoder.encoder.bn1.num_batches_tracked"]) == 0
     # DepthNet: all four disparity maps, gradient to a BatchNorm gamma deep in the encoder
     x3 = torch.rand(B, 3, H, W)
@@ -241,6 +244,7 @@ def test_eval_mode_with_autograd_is_differentiable_and_uses_running_stats(gpu_de
         assert rel(out[("disp", s)], ref[("disp", s)]) < 2e-4
     sum(ref[("disp", s)].mean() for s in range(4)).backward()
     sum(out[("disp", s)].mean() for s in range(4)).backward()
-    for n in ("encoder.encoder.layer3.0.bn2.weight", "encoder.encoder.layer2.0.downsample.1.bias", "encoder.encoder.conv1.weight",
-              "decoder.9.conv.conv.weight"):
-        assert rel(dict(dn.named_parameters())[n].grad, cd[n].grad) < 2e-3, n
+    flip = 1.0 / (B * 3 * 4 * 512) ** 0.5
+    for n in ("encoder.encoder.layer3.0.bn2.weight", "encoder.encoder.layer2.0.downsample.1.bias", "encoder.encoder.conv1.weight"):
+        assert rel(dict(dn.named_parameters())[n].grad, cd[n].grad) < 2e-3 + 2 * flip, n
+    assert rel(dict(dn.named_parameters())["decoder.9.conv.conv.weight"].grad, cd["decoder.9.conv.conv.weight"].grad) < 1e-4

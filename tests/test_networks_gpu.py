@@ -155,34 +155,50 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
 
 def test_posenet_pairs_in_one_pass_equal_two_calls(gpu_device):
     """PoseNet.forward(x, pairs=2) -- both frame pairs as one batch of 2B with per-pair BatchNorm statistics -- against
-    the reference's two calls (vo/learner_new.py:113-114): outputs, parameter gradients and the BatchNorm running
-    statistics (two momentum updates in call order) must agree."""
+    the reference's two calls (vo/learner_new.py:113-114): outputs and BatchNorm running statistics (two momentum updates
+    in call order) must agree tightly; the parameter gradients of BOTH forms are judged against an fp64 run of the oracle
+    with the fp32 oracle as the yardstick.  (Round 1 compared the two GPU forms with each other at 5e-2.  The cause of the
+    spread is not summation order as such: rounding differences flip single ReLU branches, one flip moves a gradient
+    tensor by ~1/sqrt(elements of that activation) -- 7e-3 at layer 4 of this 96x128 case -- and the 24-sample BatchNorms
+    spread it over the channel; the reference's own fp32 CPU arithmetic shows the same steps against fp64,
+    tools/grad_truth.py / profiles/r02_grad_truth_pose_pairs_96.txt.)"""
     from deep_visual_slam_amd.posenet_single import PoseNet
+    from oracle import networks as ON
     torch.manual_seed(21)
-    a = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
+    a = PoseNet(18, pretrained=False, num_input_images=2)
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    a = a.to(gpu_device).train()
     b = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
     b.load_state_dict(a.state_dict())
     B, H, W = 3, 96, 128
-    x1, x2 = torch.rand(B, 6, H, W, device=gpu_device), torch.rand(B, 6, H, W, device=gpu_device)
-    w = torch.randn(2 * B, 1, 1, 6, device=gpu_device)
+    x1c, x2c = torch.rand(B, 6, H, W), torch.rand(B, 6, H, W)
+    wc = torch.randn(2 * B, 1, 1, 6)
+    x1, x2, w = x1c.to(gpu_device), x2c.to(gpu_device), wc.to(gpu_device)
     aa1, t1 = a(x1)
     aa2, t2 = a(x2)
     (torch.cat([torch.cat([aa1, t1], -1), torch.cat([aa2, t2], -1)]) * w).sum().backward()
     aab, tb = b(torch.cat([x1, x2]), pairs=2)
     (torch.cat([aab, tb], -1) * w).sum().backward()
     assert rel(aab, torch.cat([aa1, aa2])) < 1e-5 and rel(tb, torch.cat([t1, t2])) < 1e-5
-    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        if pa.grad is not None:
-            # the two sides sum in different orders (other tiles / split-K partitions for a batch of 2B, float atomics), and
-            # the stem sits at the end of a 40-layer backward chain through BatchNorms with 24-sample batches: the
-            # difference reaches ~2e-2 there (5e-3 run to run).  A grouping bug -- statistics over the whole batch instead
-            # of per pair -- is an O(1) error.
-            assert rel(pb.grad, pa.grad) < 5e-2, n
     for (n, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
         if "num_batches_tracked" in n:
             assert int(ba) == int(bb) == 2, n
         elif ".fc." not in n:
             assert rel(bb, ba) < 1e-5, n
+    # the truth and the yardstick
+    grads = {}
+    for dtype in (torch.float64, torch.float32):
+        s = {k: (v.to(dtype) if v.is_floating_point() else v).clone().requires_grad_(v.is_floating_point() and ".fc." not in k and "running" not in k)
+             for k, v in sd.items()}
+        o1, o2 = ON.posenet(x1c.to(dtype), s, train=True), ON.posenet(x2c.to(dtype), s, train=True)
+        (torch.cat([torch.cat(o1, -1), torch.cat(o2, -1)]) * wc.to(dtype)).sum().backward()
+        grads[dtype] = {k: v.grad for k, v in s.items() if v.requires_grad}
+    worst_cpu = max(rel(grads[torch.float32][k], grads[torch.float64][k]) for k in grads[torch.float64])
+    flip = 1.0 / (B * 3 * 4 * 256) ** 0.5              # one branch flip in the smallest ReLU map (pose decoder, 3x4)
+    for net, tag in ((a, "two calls"), (b, "pairs=2")):
+        worst = max((rel(p.grad, grads[torch.float64][n]), n) for n, p in net.named_parameters() if p.grad is not None)
+        print("%s: worst gradient error vs fp64 %.2e at %s (fp32 CPU oracle: %.2e)" % (tag, worst[0], worst[1], worst_cpu))
+        assert worst[0] <= 3.0 * worst_cpu + 2.0 * flip, (tag, worst, worst_cpu)
 
 
 @pytest.mark.parametrize("name", ["layers_level_skip", "layers_level_noskip"])

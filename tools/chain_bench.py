@@ -25,5 +25,5 @@ torch.cuda.synchronize()
 prof = dp.profile_read()
 dp.profile_enable(False)
 bytes_fwd = {4: 45.87e6, 1: 12.29e6}.get(S, 45.87e6 * S / 4) * B
-out = {k: {"avg_ms": ms / n, "GBps_algorithmic": bytes_fwd / (ms / n * 1e-3) / 1e9} for k, (ms, n) in prof.items()}
+out = {k: {"avg_ms": ms / n, "GBps_algorithmic": bytes_fwd / (ms / n * 1e-3) / 1e9} for k, (ms, n, _w) in prof.items()}
 print(json.dumps({"B": B, "S": S, **out}))
