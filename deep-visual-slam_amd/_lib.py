@@ -41,6 +41,11 @@ class ChainBwdIO(C.Structure):
                 ("bwd_partials", _vp), ("scale_begin", C.c_int), ("scale_end", C.c_int), ("phase", C.c_int)]
 
 
+class DepthLossCfg(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("num_scales", C.c_int),
+                ("hs", C.c_int * MAX_SCALES), ("ws", C.c_int * MAX_SCALES), ("variance_focus", C.c_float)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int)]
@@ -97,6 +102,9 @@ _SIGNATURES = {
     "dvs_smooth_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dvs_smooth_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
     "dvs_smooth_bwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
+    "dvs_depth_loss_workspace": (C.c_size_t, [C.POINTER(DepthLossCfg)]),
+    "dvs_depth_loss_fwd": (C.c_int, [C.POINTER(DepthLossCfg), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dvs_depth_loss_bwd": (C.c_int, [C.POINTER(DepthLossCfg), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]),
 }
 
 _lib = None

@@ -324,3 +324,57 @@ class _Smooth(torch.autograd.Function):
 
 def smooth_loss(disp, img):
     return _Smooth.apply(disp, img)
+
+
+# ------------------------------------------------------------------- supervised depth learner
+class _DepthLoss(torch.autograd.Function):
+    """(silog_s, smooth_s) for every scale of DepthLearner.multi_scale_loss (depth/depth_learner.py:97-117) in one
+    forward and one backward launch: out = [silog_0..S-1, smooth_0..S-1]."""
+
+    @staticmethod
+    def forward(ctx, gt, mask, rgb, variance_focus, *preds):
+        gt, rgb = _f32c(gt), _f32c(rgb)
+        preds = [_f32c(d) for d in preds]
+        B, _, H, W = rgb.shape
+        if mask.dtype != torch.uint8:
+            mask = mask.to(torch.uint8)
+        mask = mask.contiguous()
+        if gt.numel() != B * H * W or mask.numel() != B * H * W:
+            raise _lib.DvsError("depth loss: gt_depth / valid_mask must be [B,1,H,W] or [B,H,W] of the image size")
+        S = len(preds)
+        cfg = _lib.DepthLossCfg()
+        cfg.B, cfg.H, cfg.W, cfg.num_scales, cfg.variance_focus = B, H, W, S, variance_focus
+        for s, d in enumerate(preds):
+            if d.shape[0] != B or d.shape[1] != 1:
+                raise _lib.DvsError("depth loss: pred_depths[%d] must be [B,1,h,w]" % s)
+            cfg.hs[s], cfg.ws[s] = d.shape[2], d.shape[3]
+        l = _lib.lib()
+        nbytes = l.dvs_depth_loss_workspace(C.byref(cfg))
+        if nbytes == 0:
+            raise _lib.DvsError("dvs_depth_loss_workspace: %s" % l.dvs_last_error().decode())
+        ws = torch.empty(nbytes // 4, device=rgb.device, dtype=torch.float32)
+        out = torch.empty(2 * S, device=rgb.device, dtype=torch.float32)
+        pp = (C.c_void_p * S)(*[ptr(d) for d in preds])
+        check(l.dvs_depth_loss_fwd(C.byref(cfg), pp, ptr(gt), ptr(mask), ptr(rgb), ptr(ws), ptr(out), _lib.stream()),
+              "dvs_depth_loss_fwd")
+        ctx.save_for_backward(gt, mask, rgb, ws, *preds)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        gt, mask, rgb, ws, *preds = ctx.saved_tensors
+        S = len(preds)
+        d_preds = [torch.empty_like(d) for d in preds]
+        pp = (C.c_void_p * S)(*[ptr(d) for d in preds])
+        dd = (C.c_void_p * S)(*[ptr(d) for d in d_preds])
+        check(_lib.lib().dvs_depth_loss_bwd(C.byref(ctx.cfg), pp, ptr(gt), ptr(mask), ptr(rgb), ptr(ws), ptr(_f32c(d_out)), dd,
+                                            _lib.stream()), "dvs_depth_loss_bwd")
+        return (None, None, None, None, *d_preds)
+
+
+def depth_multiscale_losses(pred_depths, gt_depth, rgb, valid_mask, variance_focus=0.85):
+    """(silog [S], smooth [S]) of the upsampled per-scale depth predictions (depth/depth_learner.py:97-117)."""
+    out = _DepthLoss.apply(gt_depth, valid_mask, rgb, float(variance_focus), *pred_depths)
+    S = len(pred_depths)
+    return out[:S], out[S:]

@@ -329,6 +329,30 @@ int dvs_smooth_fwd(const float* disp, const float* img, float* out, float* works
 int dvs_smooth_bwd(const float* disp, const float* img, const float* d_out, float* d_disp, int B,
                    int C, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * the supervised depth learner's multi-scale loss, depth/depth_learner.py:51-117
+ *     (DepthLearner.multi_scale_loss: F.interpolate bilinear of each scale's depth to (H, W), get_smooth_loss on the
+ *     mean-normalised map, silog_loss over the valid pixels).  One forward launch for all scales, one backward launch.
+ *       pred_depth[s] [B,1,hs,ws] (disp_to_depth already applied, as the reference's pred_depths list),
+ *       gt_depth [B,1,H,W], valid_mask [B,1,H,W] bytes (non-zero = valid), rgb [B,3,H,W];
+ *       out [2*S] (device): silog_s for s < S, then smooth_s;  d_out [2*S]: their upstream gradients;
+ *       d_pred_depth[s] [B,1,hs,ws], overwritten.  workspace: dvs_depth_loss_workspace bytes, filled by the forward
+ *       call and read by the backward call.  No valid pixel at all gives NaN, as the reference's mean over nothing does.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B, H, W;
+    int num_scales;
+    int hs[DVS_MAX_SCALES];
+    int ws[DVS_MAX_SCALES];
+    float variance_focus;            /* 0.85, depth_learner.py:80 */
+} dvs_depth_loss_cfg;
+size_t dvs_depth_loss_workspace(const dvs_depth_loss_cfg* cfg);
+int dvs_depth_loss_fwd(const dvs_depth_loss_cfg* cfg, const float* const* pred_depth, const float* gt_depth,
+                       const unsigned char* valid_mask, const float* rgb, float* workspace, float* out, void* stream);
+int dvs_depth_loss_bwd(const dvs_depth_loss_cfg* cfg, const float* const* pred_depth, const float* gt_depth,
+                       const unsigned char* valid_mask, const float* rgb, float* workspace, const float* d_out,
+                       float* const* d_pred_depth, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

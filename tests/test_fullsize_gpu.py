@@ -254,19 +254,29 @@ def _median(v):
 
 def _judge_grads(tag, module, sd32, sd64, n_min_relu, worst_n=3):
     """n_min_relu: elements of the smallest ReLU output on the path (the unit of one branch flip: 1/sqrt(n))."""
-    rows = []
+    # judged per LAYER (weight and bias gradients concatenated): a bias gradient is one number per channel -- for the
+    # 1-channel disparity heads a single, heavily cancelling sum over every pixel -- whose rounding error is only
+    # meaningful against the scale of its layer's gradient, not against itself
+    groups = {}
     for n, p in module.named_parameters():
         g64 = sd64[n].grad
         if ".fc." in n or g64 is None:
             assert p.grad is None and sd32[n].grad is None, n        # unused tensors: no gradient on either side
             continue
         assert p.grad is not None, n
-        rows.append((rel(p.grad, g64), rel(sd32[n].grad, g64), n))
+        assert p.grad.shape == g64.shape, n
+        groups.setdefault(n.rsplit(".", 1)[0], []).append((p.grad.detach().double().cpu().reshape(-1),
+                                                           sd32[n].grad.double().reshape(-1), g64.reshape(-1)))
+    rows = []
+    for n, parts in groups.items():
+        g, c, t = (torch.cat([q[i] for q in parts]) for i in range(3))
+        den = float(t.norm()) + 1e-300
+        rows.append((float((g - t).norm()) / den, float((c - t).norm()) / den, n))
     worst_cpu = max(r[1] for r in rows)
     med_gpu, med_cpu = _median([r[0] for r in rows]), _median([r[1] for r in rows])
     for e, c, n in sorted(rows, reverse=True)[:worst_n]:
         report("%s grad vs f64: gpu %.2e cpu32 %.2e  %s" % (tag, e, c, n))
-    report("%s grad vs f64 over %d tensors: worst gpu %.2e cpu32 %.2e, median gpu %.2e cpu32 %.2e"
+    report("%s grad vs f64 over %d layers: worst gpu %.2e cpu32 %.2e, median gpu %.2e cpu32 %.2e"
            % (tag, len(rows), max(r[0] for r in rows), worst_cpu, med_gpu, med_cpu))
     # per tensor: within 3x the reference arithmetic's own worst tensor, plus two branch flips of the smallest ReLU map (the
     # two implementations do not flip the same elements); in the median: within 2x the reference's median

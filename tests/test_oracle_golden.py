@@ -166,3 +166,23 @@ def test_decoder_level_matches_reference_layers(name):
         assert torch.allclose(grads[1], T("d_skip"), atol=1e-5, rtol=1e-4)
     for k, gr in zip(keys, grads[len(ins):]):
         assert torch.allclose(gr, T("d_" + k), atol=1e-4, rtol=1e-4), k
+
+
+@pytest.mark.parametrize("name", ["depth_learner_b2_48x64.npz", "depth_learner_b3_40x56_ragged.npz"])
+def test_depth_learner_oracle_matches_reference(name):
+    """oracle/depth_loss.py against vectors produced by the reference's depth/depth_learner.py
+    (tests/golden/make_golden_depth.py): the three losses and the gradients w.r.t. the four disparity maps."""
+    from oracle import depth_loss as OD
+    rec = load_golden(name)
+    T = lambda k: torch.from_numpy(rec[k])
+    disps = [T("disp%d" % s).requires_grad_(True) for s in range(4)]
+    preds = [OD.disp_to_depth(d, 0.1, 10.0) for d in disps]
+    for s in range(4):
+        close(preds[s], rec["pred_depth%d" % s], rtol=1e-6)
+    total, silog, smooth, _, _ = OD.multi_scale_loss(preds, T("gt"), T("rgb"), T("mask").bool())
+    close(total, rec["total"], rtol=1e-5)
+    close(silog, rec["silog"], rtol=1e-5)
+    close(smooth, rec["smooth"], rtol=1e-5)
+    total.backward()
+    for s in range(4):
+        close(disps[s].grad, rec["d_disp%d" % s], atol=1e-7, rtol=1e-3)
