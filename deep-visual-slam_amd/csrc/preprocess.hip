@@ -1,0 +1,190 @@
+// the input side of the path -- what the reference does per sample on CPU workers
+// (vo/dataset/common.py:38-92: PIL image -> ToTensor -> ColorJitter on the three frames) moved behind the H2D copy, so
+// that host memory and PCIe carry uint8 frames (1/4 of the fp32 bytes) and the CPU workers only decode:
+//
+//   dvs_u8_to_f32_planar   uint8 HWC (RGB or BGR) -> fp32 planar CHW in [0,1]: transforms.ToTensor (common.py:77), and
+//                          the BGR -> RGB + /255 of slam/network.py:42-50 for the MonoVO adapter;
+//   dvs_color_jitter       torchvision ColorJitter(brightness, contrast, saturation, hue) (common.py:31-37,79-81) with
+//                          per-sample parameters drawn on the host: the four adjustments in the sample's random order, the
+//                          contrast step's per-image grayscale mean taken by a reduction between two elementwise passes.
+//
+// Both are pure streaming kernels (HBM-bound: 3 B in / 12 B out per pixel, and 12 B in / 12 B out per jitter pass).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ __launch_bounds__(NT) void u8_to_f32_planar_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst,
+                                                              int HW, int bgr, float scale) {
+    const int n = blockIdx.y;
+    const unsigned char* s = src + (size_t)n * HW * 3;
+    float* d = dst + (size_t)n * 3 * HW;
+    // 4 pixels = 12 source bytes = three aligned 32-bit words per lane
+    const int quads = HW >> 2;
+    for (int q = blockIdx.x * NT + threadIdx.x; q < quads; q += gridDim.x * NT) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(s) + (size_t)q * 3;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        unsigned char by[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            by[k] = (w0 >> (8 * k)) & 0xff;
+            by[4 + k] = (w1 >> (8 * k)) & 0xff;
+            by[8 + k] = (w2 >> (8 * k)) & 0xff;
+        }
+        float4 c0, c1, c2;
+        c0.x = by[0] * scale; c1.x = by[1] * scale; c2.x = by[2] * scale;
+        c0.y = by[3] * scale; c1.y = by[4] * scale; c2.y = by[5] * scale;
+        c0.z = by[6] * scale; c1.z = by[7] * scale; c2.z = by[8] * scale;
+        c0.w = by[9] * scale; c1.w = by[10] * scale; c2.w = by[11] * scale;
+        float4* o0 = reinterpret_cast<float4*>(d + (bgr ? 2 : 0) * (size_t)HW) + q;
+        float4* o1 = reinterpret_cast<float4*>(d + (size_t)HW) + q;
+        float4* o2 = reinterpret_cast<float4*>(d + (bgr ? 0 : 2) * (size_t)HW) + q;
+        *o0 = c0;
+        *o1 = c1;
+        *o2 = c2;
+    }
+    // tail (HW not a multiple of 4)
+    for (int i = (quads << 2) + blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) {
+        d[(bgr ? 2 : 0) * (size_t)HW + i] = s[i * 3 + 0] * scale;
+        d[(size_t)HW + i] = s[i * 3 + 1] * scale;
+        d[(bgr ? 0 : 2) * (size_t)HW + i] = s[i * 3 + 2] * scale;
+    }
+}
+
+// ---- ColorJitter: torchvision.transforms.functional (tensor path) restated ----------------------------------------
+struct JitterRec {          // one per image: 32 bytes
+    int order[4];           // adjustment ids in application order: 0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = none
+    float factor[4];        // brightness, contrast, saturation factors; hue shift -- indexed by adjustment id
+};
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float gray_of(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+
+__device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float hf) {
+    // _rgb2hsv / _hsv2rgb of torchvision.transforms._functional_tensor
+    const float maxc = fmaxf(r, fmaxf(g, b)), minc = fminf(r, fminf(g, b));
+    const bool eqc = maxc == minc;
+    const float cr = maxc - minc;
+    const float ones = 1.f;
+    const float s = cr / (eqc ? ones : maxc);
+    const float crd = eqc ? ones : cr;
+    const float rc = (maxc - r) / crd, gc = (maxc - g) / crd, bc = (maxc - b) / crd;
+    const float hr = (maxc == r) ? (bc - gc) : 0.f;
+    const float hg = ((maxc == g) && (maxc != r)) ? (2.f + rc - bc) : 0.f;
+    const float hb = ((maxc != g) && (maxc != r)) ? (4.f + gc - rc) : 0.f;
+    float h = (hr + hg + hb) / 6.f + 1.f;
+    h = fmodf(h, 1.f);
+    h = h + hf;
+    h = h - floorf(h);                        // torch's  % 1.0  (result in [0, 1))
+    const float v = maxc;
+    const float i6 = floorf(h * 6.f);
+    const float f = h * 6.f - i6;
+    int i = (int)i6;
+    i = i % 6;
+    const float p = clamp01(v * (1.f - s)), q = clamp01(v * (1.f - f * s)), t = clamp01(v * (1.f - (1.f - f) * s));
+    switch (i) {
+        case 0: r = v; g = t; b = p; break;
+        case 1: r = q; g = v; b = p; break;
+        case 2: r = p; g = v; b = t; break;
+        case 3: r = p; g = q; b = v; break;
+        case 4: r = t; g = p; b = v; break;
+        default: r = v; g = p; b = q; break;
+    }
+}
+
+__device__ __forceinline__ void apply_op(int op, const float* factor, float mean, float& r, float& g, float& b) {
+    if (op == 0) {                               // adjust_brightness: blend with zeros
+        const float k = factor[0];
+        r = clamp01(r * k); g = clamp01(g * k); b = clamp01(b * k);
+    } else if (op == 1) {                        // adjust_contrast: blend with the image's mean gray level
+        const float k = factor[1], m = (1.f - k) * mean;
+        r = clamp01(k * r + m); g = clamp01(k * g + m); b = clamp01(k * b + m);
+    } else if (op == 2) {                        // adjust_saturation: blend with the pixel's gray level
+        const float k = factor[2], m = (1.f - k) * gray_of(r, g, b);
+        r = clamp01(k * r + m); g = clamp01(k * g + m); b = clamp01(k * b + m);
+    } else if (op == 3) {
+        hue_shift(r, g, b, factor[3]);
+    }
+}
+
+// phase 0: the adjustments in front of the contrast step, + per-workgroup partial sums of the gray level (the contrast
+//          step's mean); phase 1: the contrast step and everything behind it.  An image without a contrast step is
+//          finished by phase 0.
+__global__ __launch_bounds__(NT) void color_jitter_kernel(float* __restrict__ img, const JitterRec* __restrict__ recs,
+                                                          float* __restrict__ partials, int HW, int phase) {
+    __shared__ float sRed[NT / 64];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const JitterRec rec = recs[n];
+    int cpos = 4;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) cpos = (rec.order[k] == 1) ? k : cpos;
+    const int k0 = phase ? cpos : 0, k1 = phase ? 4 : cpos;
+    float mean = 0.f;
+    if (phase) {
+        if (cpos == 4) return;                   // nothing left for this image
+        float v = 0.f;
+        for (int j = tid; j < (int)gridDim.x; j += NT) v += partials[(size_t)n * gridDim.x + j];
+        v = dvs::wave_sum(v);
+        if ((tid & 63) == 0) sRed[tid >> 6] = v;
+        __syncthreads();
+        mean = (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / (float)HW;
+        __syncthreads();
+    }
+    float* p = img + (size_t)n * 3 * HW;
+    float gsum = 0.f;
+    for (int i = blockIdx.x * NT + tid; i < HW; i += gridDim.x * NT) {
+        float r = p[i], g = p[HW + i], b = p[2 * HW + i];
+        for (int k = k0; k < k1; ++k) apply_op(rec.order[k], rec.factor, mean, r, g, b);
+        if (k1 > k0) {
+            p[i] = r;
+            p[HW + i] = g;
+            p[2 * HW + i] = b;
+        }
+        gsum += gray_of(r, g, b);
+    }
+    if (!phase) {
+        gsum = dvs::wave_sum(gsum);
+        if ((tid & 63) == 0) sRed[tid >> 6] = gsum;
+        __syncthreads();
+        if (tid == 0) partials[(size_t)n * gridDim.x + blockIdx.x] = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+    }
+}
+
+inline int jitter_blocks(int HW) {
+    int b = (HW + NT * 8 - 1) / (NT * 8);
+    return b < 1 ? 1 : (b > 256 ? 256 : b);      // <= NT partial sums per image (phase 1 adds them with one pass)
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_u8_to_f32_planar(const unsigned char* src, float* dst, int N, int H, int W, int bgr, void* stream) {
+    DVS_REQUIRE(src && dst && N > 0 && H > 0 && W > 0, "dvs_u8_to_f32_planar: bad argument");
+    DVS_REQUIRE((reinterpret_cast<uintptr_t>(src) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ((size_t)H * W) % 4 == 0,
+                "dvs_u8_to_f32_planar: 4-byte aligned source, 16-byte aligned destination and H*W %% 4 == 0 required");
+    const int HW = H * W;
+    int blocks = (HW / 4 + NT - 1) / NT;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(u8_to_f32_planar_kernel, dim3(blocks, N), dim3(NT), 0, static_cast<hipStream_t>(stream), src, dst, HW, bgr,
+                       1.0f / 255.0f);
+    return dvs::check_launch("dvs_u8_to_f32_planar");
+}
+
+size_t dvs_color_jitter_workspace(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)N * jitter_blocks(H * W) * sizeof(float);
+}
+
+int dvs_color_jitter(float* images, const void* records, float* workspace, int N, int H, int W, void* stream) {
+    DVS_REQUIRE(images && records && workspace && N > 0 && H > 0 && W > 0, "dvs_color_jitter: bad argument");
+    const int HW = H * W, blocks = jitter_blocks(HW);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const JitterRec* recs = static_cast<const JitterRec*>(records);
+    hipLaunchKernelGGL(color_jitter_kernel, dim3(blocks, N), dim3(NT), 0, st, images, recs, workspace, HW, 0);
+    hipLaunchKernelGGL(color_jitter_kernel, dim3(blocks, N), dim3(NT), 0, st, images, recs, workspace, HW, 1);
+    return dvs::check_launch("dvs_color_jitter");
+}
+
+}  // extern "C"

@@ -353,6 +353,22 @@ int dvs_depth_loss_bwd(const dvs_depth_loss_cfg* cfg, const float* const* pred_d
                        const unsigned char* valid_mask, const float* rgb, float* workspace, const float* d_out,
                        float* const* d_pred_depth, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * the input side of the path, vo/dataset/common.py:38-92, behind the H2D copy
+ *   dvs_u8_to_f32_planar: src uint8 [N,H,W,3] (RGB, or BGR with bgr != 0) -> dst fp32 [N,3,H,W] (RGB planes) / 255:
+ *       transforms.ToTensor of common.py:77; with bgr the preprocessing of slam/network.py:42-50.  H*W % 4 == 0,
+ *       src 4-byte and dst 16-byte aligned.
+ *   dvs_color_jitter: torchvision ColorJitter (common.py:31-37,79-81) in place on images fp32 [N,3,H,W] in [0,1].
+ *       records (device): N x { int order[4]; float factor[4]; } -- order = adjustment ids in application order
+ *       (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 none), factor[id] = that adjustment's factor (hue: the shift
+ *       in [-0.5, 0.5]).  Images that share a record's values get the same jitter (the reference jitters the three frames
+ *       of a sample together); the contrast step's mean gray level is per image.  workspace: dvs_color_jitter_workspace
+ *       bytes.
+ * ------------------------------------------------------------------------------------------- */
+int dvs_u8_to_f32_planar(const unsigned char* src, float* dst, int N, int H, int W, int bgr, void* stream);
+size_t dvs_color_jitter_workspace(int N, int H, int W);
+int dvs_color_jitter(float* images, const void* records, float* workspace, int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,33 @@ def test_primitives_fail_loudly_without_gpu_or_kernel():
                  lambda: nn_ops.upsample_nearest2x(x)):
         with pytest.raises(_lib.DvsError):
             call()
+
+
+# ------------------------------------------------------------------------------------------ input pipeline (host side)
+def test_jitter_records_and_intrinsics_pyramid():
+    import numpy as np
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.input_pipeline import JitterParams, intrinsics_pyramid
+    jp = JitterParams(5, np.random.default_rng(0))
+    assert jp.order.shape == (5, 4) and all(sorted(r) == [0, 1, 2, 3] for r in jp.order.tolist())
+    assert (np.abs(jp.factor[:, :3] - 1) <= 0.3).all() and (np.abs(jp.factor[:, 3]) <= 0.2).all()
+    jp.apply[:] = [True, False, True, True, False]
+    rec = jp.records(3)
+    assert rec.shape == (15, 8) and rec.dtype == np.int32
+    assert (rec[3:6, :4] == -1).all() and (rec[0:3, :4] == jp.order[0]).all()           # frames of a sample share a record
+    assert np.array_equal(rec[7, 4:].view(np.float32), jp.factor[2])
+    # K / inv_K pyramid: same numbers as the synthetic-sample builder that follows vo/dataset/common.py:65-75
+    ref = synth.intrinsics(2, 480, 640)
+    got = intrinsics_pyramid(ref[("K", 0)].numpy(), 480, 640)
+    for s in range(4):
+        assert torch.allclose(got[("K", s)], ref[("K", s)], atol=1e-6) and torch.allclose(got[("inv_K", s)], ref[("inv_K", s)], atol=1e-8)
+
+
+def test_color_jitter_oracle_identity_and_range():
+    """The restated ColorJitter: factor 1 / shift 0 is the identity (up to the hsv round trip), output stays in [0, 1]."""
+    from oracle import input_pipeline as OI
+    img = torch.rand(3, 20, 30, generator=torch.Generator().manual_seed(0))
+    same = OI.color_jitter(img, [0, 1, 2, 3], [1.0, 1.0, 1.0, 0.0])
+    assert float((same - img).abs().max()) < 1e-5
+    out = OI.color_jitter(img, [3, 1, 0, 2], [1.3, 0.7, 1.3, -0.2])
+    assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and float((out - img).abs().max()) > 0.05
