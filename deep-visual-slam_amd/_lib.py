@@ -105,6 +105,12 @@ _SIGNATURES = {
     "dvs_u8_to_f32_planar": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_color_jitter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dvs_color_jitter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_attention_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_vit_patchify": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_vit_assemble": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_resize_bilinear_ac": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_deconv_shuffle": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_depth_loss_workspace": (C.c_size_t, [C.POINTER(DepthLossCfg)]),
     "dvs_depth_loss_fwd": (C.c_int, [C.POINTER(DepthLossCfg), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvs_depth_loss_bwd": (C.c_int, [C.POINTER(DepthLossCfg), C.POINTER(_vp), _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _vp]),

@@ -16,7 +16,7 @@ import torch
 from . import _lib, gradsink, zeropool
 from ._lib import ConvDesc, ConvFusion, check, ptr
 
-ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "gelu": 4}
 CL = torch.channels_last
 
 

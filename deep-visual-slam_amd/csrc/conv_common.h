@@ -23,7 +23,7 @@ constexpr int BK = 32;          // k per LDS stage
 constexpr int LDK = BK + 4;     // padded LDS row (floats)
 constexpr int NT = 256;         // 4 waves
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3, ACT_GELU = 4 };   // GELU: forward only (ViT MLP)
 enum Pad { PAD_ZERO = 0, PAD_REFLECT = 1 };
 // how the logical input is stored
 enum InMode {
@@ -88,6 +88,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case ACT_RELU: return fmaxf(v, 0.f);
         case ACT_ELU: return v > 0.f ? v : expm1f(v);
         case ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));      // nn.GELU() (exact erf form)
         default: return v;
     }
 }

@@ -815,6 +815,7 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
         p.t.x2 = f->x2; p.t.C1 = f->C1; p.t.in_scale = f->in_scale; p.t.in_shift = f->in_shift;
         p.t.in_relu = f->in_relu; planar = f->nchw_planar;
         p.act = f->act; p.stats = f->stats; p.res = f->residual;
+        DVS_REQUIRE(f->act >= 0 && f->act <= ACT_GELU, "dvs_conv2d_fwd: unknown activation %d", f->act);
         DVS_REQUIRE(!(f->residual && f->stats), "dvs_conv2d_fwd: residual and stats are exclusive (inference vs training)");
         DVS_REQUIRE(f->stat_groups >= 0 && f->stat_groups <= 2 && (f->stat_groups != 2 || (d->B % 2) == 0),
                     "dvs_conv2d_fwd: stat_groups is 0, 1 or 2 (2 needs an even batch)");

@@ -97,7 +97,8 @@ typedef struct {
     int in_relu;            /* then ReLU */
     int nchw_planar;        /* x is a planar [B,Cin,H,W] image (encoder conv1); any Cin */
     /* output-side fusion */
-    int act;                /* 0 none, 1 ReLU, 2 ELU(alpha=1), 3 sigmoid */
+    int act;                /* 0 none, 1 ReLU, 2 ELU(alpha=1), 3 sigmoid, 4 GELU (erf form; forward only: the ViT MLP of
+                               model/depth_anything_v2/dinov2_layers/mlp.py:35-41) */
     float* stats;           /* non-NULL: [2][Cout], += per-channel sum and sum of squares of the raw
                                (pre-bias, pre-activation) output: BatchNorm batch statistics */
     int stat_groups;        /* 0 / 1: one set of statistics; 2: stats is [2][2][Cout], the first and second half of
@@ -368,6 +369,28 @@ int dvs_depth_loss_bwd(const dvs_depth_loss_cfg* cfg, const float* const* pred_d
 int dvs_u8_to_f32_planar(const unsigned char* src, float* dst, int N, int H, int W, int bgr, void* stream);
 size_t dvs_color_jitter_workspace(int N, int H, int W);
 int dvs_color_jitter(float* images, const void* records, float* workspace, int N, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a14 / SURVEY.md 8(f) rank 1: Depth-Anything-V2 ViT-S (BASELINE.json configs[4]) -- forward kernels beside the
+ *     implicit-GEMM engine (the token GEMMs are dvs_conv2d_fwd calls on [1,1,M,K] tensors).
+ *   dvs_attention_fwd: out [B,N,heads*64] = softmax(q k^T * scale) v per head from qkv [B,N,3,heads,64] (the output of the
+ *       qkv Linear), model/depth_anything_v2/dinov2_layers/attention.py:49-62; flash style on the fp32 matrix cores.
+ *   dvs_layernorm_fwd: nn.LayerNorm(C, eps) over the last dimension of x [M,C] (block.py:53,67; dinov2.py:166).
+ *   dvs_vit_patchify: image [B,3,H,W] -> rows [B*(H/p)*(W/p)][k_padded], row = one patch in (ci, ky, kx) order, zero padded
+ *       to k_padded (>= 3 p p, % 4 == 0): the A operand of PatchEmbed.proj (patch_embed.py:69-82).
+ *   dvs_vit_assemble: x [B,Np+1,C] = cat(cls_token, patch_tokens [B,Np,C]) + pos_embed [Np+1,C] (dinov2.py:219-229).
+ *   dvs_resize_bilinear_ac: F.interpolate(mode="bilinear", align_corners=True) of an NHWC map [B,h,w,C] to [B,H,W,C]
+ *       (util/blocks.py:143, dpt.py:145).
+ *   dvs_deconv_shuffle: y [B,h*k,w*k,Cout] from g [B,h,w,k*k*Cout] = the 1x1 product of the input with the ConvTranspose2d
+ *       weight arranged [(a*k+c)*Cout+co][ci]: nn.ConvTranspose2d(kernel_size=k, stride=k) of dpt.py:60-73.
+ * ------------------------------------------------------------------------------------------- */
+int dvs_attention_fwd(const float* qkv, float* out, int B, int N, int heads, int head_dim, float scale, void* stream);
+int dvs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps, void* stream);
+int dvs_vit_patchify(const float* image, float* rows, int B, int H, int W, int patch, int k_padded, void* stream);
+int dvs_vit_assemble(const float* patch_tokens, const float* cls_token, const float* pos_embed, float* x, int B, int num_patches,
+                     int C, void* stream);
+int dvs_resize_bilinear_ac(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream);
+int dvs_deconv_shuffle(const float* g, float* y, int B, int h, int w, int k, int Cout, void* stream);
 
 #ifdef __cplusplus
 }
