@@ -1,0 +1,149 @@
+"""GPU parity of the Depth-Anything-V2 ViT-S path (a14 / BASELINE.json configs[4]; csrc/vit.hip + the implicit-GEMM engine
+through deep_visual_slam_amd.depth_anything_v2) against reference-generated goldens (encoder) and the CPU oracle (whole net).
+
+fp32 tolerances: 12 transformer blocks deep with O(1) activations -> tokens rel-L2 1e-4 (measured in the report line); the
+kernels themselves (attention, LayerNorm, resize, deconv scatter) are checked against torch at 2e-5 of the tensor max."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def relmax(a, b):
+    a, b = a.detach().float().cpu(), torch.as_tensor(b).float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("B,N,heads", [(1, 1370, 6), (2, 49, 6), (3, 33, 2), (1, 129, 12)])
+def test_attention_kernel(gpu_device, B, N, heads):
+    """softmax(q k^T / 8) v for d = 64 (attention.py:49-62): N = 1370 (518x518), ragged key / query tiles, few tokens."""
+    from deep_visual_slam_amd.depth_anything_v2 import attention
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3, heads, 64, generator=g) * 1.5
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    ref = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B * N, heads * 64)
+    out = attention(qkv.reshape(B * N, -1).to(gpu_device), B, N, heads, 64)
+    assert out.shape == ref.shape and relmax(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,C", [(1370, 384), (7, 768), (300, 1024), (5, 64)])
+def test_layernorm_kernel(gpu_device, M, C):
+    from deep_visual_slam_amd.depth_anything_v2 import layernorm
+    g = torch.Generator().manual_seed(C)
+    x, w, b = torch.randn(M, C, generator=g) * 2 + 0.5, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = layernorm(x.to(gpu_device), w.to(gpu_device), b.to(gpu_device), 1e-6)
+    assert relmax(out, F.layer_norm(x, (C,), w, b, 1e-6)) < 2e-5
+
+
+def test_gemm_epilogues(gpu_device):
+    """Token GEMMs on the implicit-GEMM engine: bias, GELU (erf form), residual; K = 384 / 1536 / padded 608."""
+    from deep_visual_slam_amd.depth_anything_v2 import gemm
+    g = torch.Generator().manual_seed(0)
+    for M, K, N, act, res in ((1370, 384, 1152, None, False), (1370, 384, 1536, "gelu", False), (2740, 1536, 384, None, True),
+                              (1369, 608, 384, None, False), (50, 384, 384, None, True)):
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g) * 0.1
+        r = torch.randn(M, N, generator=g) if res else None
+        ref = F.linear(x, w, b)
+        ref = F.gelu(ref) if act == "gelu" else ref
+        ref = ref + r if res else ref
+        w4 = w.view(N, K, 1, 1).contiguous(memory_format=torch.channels_last).to(gpu_device)
+        out = gemm(x.to(gpu_device), w4, b.to(gpu_device), act=act, residual=r.to(gpu_device) if res else None)
+        assert out.shape == ref.shape and relmax(out, ref) < 2e-5, (M, K, N, act, res, relmax(out, ref))
+
+
+def test_resize_and_deconv_kernels(gpu_device):
+    from deep_visual_slam_amd.depth_anything_v2 import conv_transpose_s, resize_bilinear_ac
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 64, 19, 19, generator=g)
+    for size in ((37, 37), (38, 38), (25, 60), (19, 19)):
+        out = resize_bilinear_ac(x.to(gpu_device).contiguous(memory_format=torch.channels_last), *size)
+        assert relmax(out, F.interpolate(x, size, mode="bilinear", align_corners=True)) < 2e-6
+    for k, ci, co in ((4, 48, 48), (2, 96, 96)):
+        xin, w, b = torch.randn(2, ci, 7, 9, generator=g), torch.randn(ci, co, k, k, generator=g) * 0.1, torch.randn(co, generator=g)
+        ref = F.conv_transpose2d(xin, w, b, stride=k)
+        wg = w.permute(2, 3, 1, 0).reshape(k * k * co, ci, 1, 1).contiguous(memory_format=torch.channels_last).to(gpu_device)
+        out = conv_transpose_s(xin.to(gpu_device).contiguous(memory_format=torch.channels_last), wg, b.repeat(k * k).to(gpu_device), k, co)
+        assert out.shape == ref.shape and relmax(out, ref) < 2e-5
+
+
+@pytest.fixture(scope="module")
+def dav2(gpu_device):
+    from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
+    from oracle.depth_anything import seeded_weights
+    net = DepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384]).eval()
+    enc = seeded_weights(net.pretrained.state_dict(), seed=0)
+    head = seeded_weights(net.depth_head.state_dict(), seed=4)
+    net.pretrained.load_state_dict(enc)
+    net.depth_head.load_state_dict(head)
+    sd = {"pretrained." + k: v for k, v in enc.items()}
+    sd.update({"depth_head." + k: v for k, v in head.items()})
+    assert sorted(sd) == sorted(net.state_dict())
+    return net.to(gpu_device), sd
+
+
+def test_dinov2_encoder_vs_reference_goldens(gpu_device, dav2):
+    """get_intermediate_layers(x, [2,5,8,11], return_class_token=True) against the reference's own outputs: the small
+    non-square image in full, 518x518 (N = 1370, the BASELINE size) by strided sample + checksums."""
+    net, _ = dav2
+    rec = load_golden("dav2_dinov2_vits.npz")
+    with torch.no_grad():
+        outs = net.pretrained.get_intermediate_layers(torch.from_numpy(rec["small/x"]).to(gpu_device), [2, 5, 8, 11], return_class_token=True)
+    for i, (tok, cls) in enumerate(outs):
+        e = rel(tok, rec["small/tok%d" % i])
+        print("dinov2 84x112 tap %d rel-L2 %.2e" % (i, e))
+        assert tok.shape == rec["small/tok%d" % i].shape and e < 1e-4 and rel(cls, rec["small/cls%d" % i]) < 1e-4
+    g = torch.Generator().manual_seed(1)
+    torch.randn(2, 3, 84, 112, generator=g)
+    x = torch.randn(1, 3, 518, 518, generator=g)
+    with torch.no_grad():
+        outs = net.pretrained.get_intermediate_layers(x.to(gpu_device), [2, 5, 8, 11], return_class_token=True)
+    for i, (tok, cls) in enumerate(outs):
+        assert tok.shape == (1, 1369, 384) and cls.shape == (1, 384)
+        e = rel(tok[0, ::37, ::7], rec["full/tok%d#sample" % i])
+        print("dinov2 518x518 tap %d sample rel-L2 %.2e" % (i, e))
+        assert e < 1e-4 and rel(cls, rec["full/cls%d" % i]) < 1e-4
+        t = tok.double().cpu().numpy()
+        assert abs((t * t).sum() - rec["full/tok%d#sq" % i]) < 2e-4 * rec["full/tok%d#sq" % i]
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 518, 518), (2, 84, 112)])
+def test_depth_anything_forward_vs_oracle(gpu_device, dav2, B, H, W):
+    """DepthAnythingV2.forward (dpt.py:192-199) -> depth [B,H,W] against the CPU oracle; the disp adapter's contract."""
+    from oracle import depth_anything as OD
+    net, sd = dav2
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(B, 3, H, W, generator=g)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = OD.depth_anything_v2(x, sd)
+        out = net(x.to(gpu_device))
+        disp = net.disp_outputs(x.to(gpu_device), scales=(0, 1))
+    assert out.shape == (B, H, W)
+    e = rel(out, ref)
+    print("depth_anything_v2 %dx%d rel-L2 %.2e max-rel %.2e" % (H, W, e, relmax(out, ref)))
+    assert e < 2e-4
+    assert disp[("disp", 0)].shape == (B, 1, H, W) and disp[("disp", 1)].shape == (B, 1, H // 2, W // 2)
+    assert float(disp[("disp", 0)].min()) >= 0.0 and float(disp[("disp", 0)].max()) <= 1.0
+
+
+def test_checkpoint_keys_and_training_mode_guard(gpu_device, dav2):
+    net, sd = dav2
+    keys = set(net.state_dict())
+    for k in ("pretrained.blocks.11.ls2.gamma", "pretrained.pos_embed", "pretrained.mask_token", "depth_head.projects.3.bias",
+              "depth_head.resize_layers.0.weight", "depth_head.scratch.refinenet4.resConfUnit1.conv1.weight",
+              "depth_head.scratch.output_conv2.2.weight", "depth_head.scratch.layer1_rn.weight"):
+        assert k in keys, k
+    from deep_visual_slam_amd import _lib
+    x = torch.randn(1, 3, 28, 28, device=gpu_device, requires_grad=True)
+    with pytest.raises(_lib.DvsError):
+        net(x)

@@ -186,3 +186,66 @@ def test_depth_learner_oracle_matches_reference(name):
     total.backward()
     for s in range(4):
         close(disps[s].grad, rec["d_disp%d" % s], atol=1e-7, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ Depth-Anything-V2 (a14)
+def _dav2_weights():
+    """Seeded weights in the reference's key layout: the product's module tree supplies the shapes (its keys are checked
+    against the reference's own state_dict keys stored in the fixture)."""
+    from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
+    from oracle.depth_anything import seeded_weights
+    net = DepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+    enc = {k: v for k, v in net.pretrained.state_dict().items()}
+    return net, seeded_weights(enc, seed=0)
+
+
+def test_dinov2_state_dict_layout_matches_reference():
+    rec = load_golden("dav2_dinov2_vits.npz")
+    net, _ = _dav2_weights()
+    sd = net.pretrained.state_dict()
+    assert sorted(sd) == [str(k) for k in rec["keys"]]
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd)] == [str(s) for s in rec["shapes"]]
+    assert sum(v.numel() for v in sd.values()) == 22056576           # SURVEY.md a14: measured on the reference
+
+
+def test_dinov2_oracle_matches_reference():
+    """oracle/depth_anything.dinov2_intermediate against the reference's DINOv2('vits').get_intermediate_layers
+    (tests/golden/make_golden_dav2.py): non-square 84x112 (bicubic pos-embed resampling) in full, 518x518 by checksums."""
+    from oracle import depth_anything as OD
+    rec = load_golden("dav2_dinov2_vits.npz")
+    _, w = _dav2_weights()
+    sd = {"pretrained." + k: v for k, v in w.items()}
+    with torch.no_grad():
+        outs = OD.dinov2_intermediate(torch.from_numpy(rec["small/x"]), sd, (2, 5, 8, 11), 6)
+    for i, (tok, cls) in enumerate(outs):
+        close(tok, rec["small/tok%d" % i], atol=2e-5, rtol=1e-4)
+        close(cls, rec["small/cls%d" % i], atol=2e-5, rtol=1e-4)
+    g = torch.Generator().manual_seed(1)
+    torch.randn(2, 3, 84, 112, generator=g)
+    x = torch.randn(1, 3, 518, 518, generator=g)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        outs = OD.dinov2_intermediate(x, sd, (2, 5, 8, 11), 6)
+    for i, (tok, cls) in enumerate(outs):
+        close(tok[0, ::37, ::7], rec["full/tok%d#sample" % i], atol=5e-5, rtol=2e-4)
+        t = tok.double().numpy()
+        assert abs((t * t).sum() - rec["full/tok%d#sq" % i]) < 1e-4 * rec["full/tok%d#sq" % i]
+        assert abs(np.abs(t).sum() - rec["full/tok%d#abs" % i]) < 1e-4 * rec["full/tok%d#abs" % i]
+
+
+def test_dpt_blocks_oracle_matches_reference():
+    from oracle import depth_anything as OD
+    from oracle.depth_anything import seeded_weights
+    rec = load_golden("dav2_dpt_blocks.npz")
+    shapes = {"fb.out_conv.weight": (64, 64, 1, 1), "fb.out_conv.bias": (64,), "l1.weight": (64, 48, 3, 3), "l4.weight": (64, 384, 3, 3)}
+    for u in ("resConfUnit1", "resConfUnit2"):
+        for c in ("conv1", "conv2"):
+            shapes["fb.%s.%s.weight" % (u, c)] = (64, 64, 3, 3)
+            shapes["fb.%s.%s.bias" % (u, c)] = (64,)
+    assert sorted(shapes) == [str(k) for k in rec["keys"]]
+    sd = seeded_weights({k: torch.empty(s) for k, s in shapes.items()}, seed=2)
+    a, b = torch.from_numpy(rec["a"]), torch.from_numpy(rec["b"])
+    close(OD.fusion_block(sd, "fb.", a, b, size=(19, 25)), rec["fuse2_size"], atol=1e-5, rtol=1e-5)
+    close(OD.fusion_block(sd, "fb.", a), rec["fuse1_x2"], atol=1e-5, rtol=1e-5)
+    close(OD.residual_conv_unit(a, sd, "fb.resConfUnit2."), rec["rcu"], atol=1e-5, rtol=1e-5)
+    close(torch.nn.functional.conv2d(torch.from_numpy(rec["l1_in"]), sd["l1.weight"], None, 1, 1), rec["l1_out"], atol=1e-5, rtol=1e-5)
