@@ -44,7 +44,7 @@ def train_config(batch, num_scales):
                           auto_mask=True, ssim_ratio=0.85, min_depth=0.1, max_depth=10.0, use_compile=False)}
 
 
-def build_gpu(batch, num_scales, device, rank):
+def build_gpu(batch, num_scales, device, rank, comm=None):
     from deep_visual_slam_amd import dp, synth
     from deep_visual_slam_amd.depthnet import DepthNet
     from deep_visual_slam_amd.learner_new import MonodepthTrainer
@@ -56,7 +56,7 @@ def build_gpu(batch, num_scales, device, rank):
     trainer = MonodepthTrainer(depth_net, pose_net, train_config(batch, num_scales), device)
     trainer.num_scales = num_scales
     hook_streams = ({id(p): trainer.pose_stream for p in pose_net.parameters()} if trainer.pose_stream is not None else None)
-    sync = dp.GradSync(flat, hook_streams=hook_streams)
+    sync = dp.GradSync(flat, hook_streams=hook_streams, comm=comm)
     opt = dp.FusedAdam(flat, lr=1e-4)
     sample = synth.throughput_sample(batch, H, W, rank=rank, device=device)
     return trainer, flat, sync, opt, sample
@@ -273,6 +273,63 @@ def inference_side(device, with_cpu):
     return res
 
 
+def dav2_side(device, with_cpu, batches=(1, 8)):
+    """BASELINE.json configs[4]: Depth-Anything-V2 ViT-S (DINOv2 encoder + DPT head) forward at 518x518 on the MI355X path
+    (deep_visual_slam_amd/depth_anything_v2.py: token GEMMs on the implicit-GEMM engine, flash attention on the fp32
+    matrix cores), seeded random weights; per-kernel-class HIP-event times give the MFMA rooflines of the attention kernel
+    and of the GEMM / convolution launches.  CPU beside it: the oracle restatement of the same forward."""
+    from deep_visual_slam_amd import dp
+    from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
+    torch.manual_seed(0)
+    net = DepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384]).to(device).eval()
+    res = {"workload": "configs[4]: Depth-Anything-V2 ViT-S forward, 518x518 (N = 1370 tokens, 12 blocks, 6 heads of 64), DPT head",
+           "unit": "frames/s", "dtype": "f32", "batches": {}}
+    for B in batches:
+        x = torch.randn(B, 3, 518, 518, device=device)
+        with torch.no_grad():
+            for _ in range(3):
+                net(x)
+            torch.cuda.synchronize()
+            n = 20
+            t0 = time.perf_counter()
+            for _ in range(n):
+                net(x)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            dp.profile_enable(True)
+            for _ in range(3):
+                net(x)
+            torch.cuda.synchronize()
+            prof = dp.profile_read()
+            dp.profile_enable(False)
+        entry = {"value": B / dt, "ms_per_forward": dt * 1e3}
+        for k, name in (("attention_fwd_kernel", "attention"), ("conv_fwd_kernel", "gemm_and_conv")):
+            if k in prof:
+                ms, cnt, fl = prof[k]
+                ach = fl / (ms * 1e-3) / 1e12
+                entry[name] = {"ms_per_forward": ms / 3, "launches_per_forward": cnt / 3, "algorithmic_gflop_per_forward": fl / 3e9,
+                               "roofline": {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": ach / MFMA_F32_PEAK_TFLOPS}}
+        res["batches"]["batch_%d" % B] = entry
+    res["value"] = res["batches"]["batch_%d" % batches[-1]]["value"]
+    if with_cpu:
+        from oracle import depth_anything as OD
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        xc = torch.randn(1, 3, 518, 518)
+        with torch.no_grad():
+            OD.depth_anything_v2(xc, sd)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                OD.depth_anything_v2(xc, sd)
+            tc = (time.perf_counter() - t0) / 3
+        res["cpu_baseline"] = {"value": 1.0 / tc, "unit": "frames/s", "cores": cores, "kind": "port",
+                               "sample": "3 timed + 1 warm-up forwards of one 518x518 frame, oracle/depth_anything.py on PyTorch-CPU fp32, "
+                                         "%.3f s/frame" % tc}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +364,12 @@ def main():
     rehearse = os.environ.get("DVS_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    if world > 1 and not rehearse:
+        # One rank per GPU: the step uses four compute streams and the all-reduce a fifth.  HIP maps a process's streams onto
+        # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so give the all-reduce a
+        # queue of its own (5-8 queues measured neutral for the single-GPU step).  Must be set before
+        # the HIP runtime initialises, i.e. before the first torch.cuda call below.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -323,7 +386,10 @@ def main():
         dist.barrier()
     from deep_visual_slam_amd import dp
 
-    trainer, flat, sync, opt, sample = build_gpu(batch, num_scales, device, rank)
+    comm = None
+    if world > 1 and os.environ.get("DVS_ALLREDUCE", "torch") == "rccl" and not rehearse:
+        comm = dp.RcclComm(device)                # direct RCCL on a stream (hardware queue) of its own
+    trainer, flat, sync, opt, sample = build_gpu(batch, num_scales, device, rank, comm=comm)
 
     def barrier():
         if world > 1:
@@ -423,7 +489,9 @@ def main():
                "config": {"workload": cfg["name"], "per_gpu_batch": batch, "global_batch": batch * world,
                           "num_scales": num_scales, "image": "%dx%d" % (W, H),
                           "parallelism": "dp%d" % world,
-                          "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient"},
+                          "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient",
+                          "allreduce": (None if world == 1 else ("rccl-direct" if comm is not None else "torch.distributed " + dist.get_backend())),
+                          "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
                "loss": loss_val, "loss_check": check,
                "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
                "conv_kernels": conv_summary,
@@ -474,6 +542,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"]["configs[0]"] = inference_side(device, not args.no_cpu_baseline)
+            out["other_configs"]["configs[4]"] = dav2_side(device, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -11,6 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdvslam_hip.so")
+RCCL_LIB = os.path.join(HERE, "libdvslam_rccl.so")          # include/dvslam_rccl.h: kept apart so single-GPU users never load RCCL
+RCCL_SRC = os.path.join(CSRC, "rccl", "allreduce.cpp")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
@@ -62,7 +64,25 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    build_rccl(force, verbose)
     return LIB
+
+
+def build_rccl(force=False, verbose=True):
+    """libdvslam_rccl.so: the RCCL all-reduce entry points of include/dvslam_rccl.h (host code only, links librccl)."""
+    hdr = os.path.join(os.path.dirname(HERE), "include", "dvslam_rccl.h")
+    if (not force and os.path.exists(RCCL_LIB) and os.path.getmtime(RCCL_LIB) >= os.path.getmtime(RCCL_SRC)
+            and os.path.getmtime(RCCL_LIB) >= os.path.getmtime(hdr)):
+        return RCCL_LIB
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(rocm, "include"), RCCL_SRC, "-o", RCCL_LIB,
+           "-L" + os.path.join(rocm, "lib"), "-lrccl", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (RCCL_SRC, r.stdout, r.stderr))
+    return RCCL_LIB
 
 
 if __name__ == "__main__":

@@ -308,7 +308,12 @@ int dvs_attention_fwd(const float* qkv, float* out, int B, int N, int heads, int
     DVS_REQUIRE(head_dim == HD, "dvs_attention_fwd: head dimension 64 only (got %d)", head_dim);
     DVS_REQUIRE((double)B * N * 3 * heads * HD < 2147483648.0, "dvs_attention_fwd: qkv must have fewer than 2^31 elements");
     AttnParams p{qkv, out, B, N, heads, scale};
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, static_cast<hipStream_t>(stream), p);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        dvs::ProfScope prof(dvs::SLOT_ATTN, st);
+        prof.work(4.0 * B * heads * (double)N * N * HD);      // q k^T and p v: 2 N^2 d flops each
+        hipLaunchKernelGGL(attention_fwd_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
+    }
     return dvs::check_launch("dvs_attention_fwd");
 }
 

@@ -81,10 +81,66 @@ class FlatParams:
                     p._dvs_sink.grad = p.grad
 
 
-class GradSync:
-    """Bucketed sum all-reduce of FlatParams.grads, overlapped with backward."""
+class RcclComm:
+    """Direct RCCL communicator for the gradient arena (include/dvslam_rccl.h: dvs_allreduce_{init,run,destroy}).
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None, hook_streams=None):
+    The all-reduce runs on `self.stream`, a HIP stream this object owns -- so it has a hardware queue of its own next to
+    the step's compute streams and the caller orders it with stream waits -- instead of the
+    internal stream of torch.distributed's process group.  The 128-byte rendezvous token is created by rank 0 and
+    broadcast over the torch.distributed group that already exists (any backend)."""
+
+    def __init__(self, device, group=None):
+        from . import _rccl
+        self._rccl = _rccl
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        l = _rccl.lib()
+        token = [None]
+        if self.rank == 0:
+            buf = (C.c_ubyte * _rccl.UNIQUE_ID_BYTES)()
+            _rccl.check(l.dvs_allreduce_unique_id(buf), "dvs_allreduce_unique_id")
+            token[0] = bytes(buf)
+        if self.world > 1:
+            dist.broadcast_object_list(token, src=0, group=group)
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            handle = C.c_void_p()
+            idbuf = (C.c_ubyte * _rccl.UNIQUE_ID_BYTES).from_buffer_copy(token[0])
+            _rccl.check(l.dvs_allreduce_init(C.byref(handle), idbuf, self.world, self.rank), "dvs_allreduce_init")
+            self.handle = handle
+            self.stream = torch.cuda.Stream(device=self.device)
+
+    def all_reduce_(self, tensor):
+        """In-place sum over the ranks, enqueued on self.stream AFTER everything the current stream has enqueued."""
+        if not (tensor.is_cuda and tensor.is_contiguous() and tensor.dtype == torch.float32):
+            raise _lib.DvsError("RcclComm.all_reduce_: contiguous fp32 GPU tensor expected")
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._rccl.check(self._rccl.lib().dvs_allreduce_run(self.handle, tensor.data_ptr(), tensor.numel(), self.stream.cuda_stream),
+                         "dvs_allreduce_run")
+        tensor.record_stream(self.stream)
+
+    def wait(self):
+        """The current stream waits for every all-reduce enqueued so far."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self._rccl.check(self._rccl.lib().dvs_allreduce_destroy(self.handle), "dvs_allreduce_destroy")
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GradSync:
+    """Bucketed sum all-reduce of FlatParams.grads, overlapped with backward.  `comm`: an RcclComm for the direct RCCL
+    path (DVS_ALLREDUCE=rccl in bench.py); default = torch.distributed's all_reduce on the group's backend."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, hook_streams=None, comm=None):
+        self.comm = comm
         """hook_streams: optional {id(param): torch.cuda.Stream}.  Autograd creates a parameter's AccumulateGrad node
         -- and binds it to the then-current stream -- when the hook is registered; parameters whose backward runs on
         another stream (PoseNet's, see MonodepthTrainer.pose_stream) should be registered under that stream, otherwise
@@ -158,9 +214,14 @@ class GradSync:
                 # the bucket's gradients were written on the compute and side streams of ITS network only: wait for
                 # those, not for the other network's backward
                 gradsink.fence_for(self._members[b])
-                self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                  async_op=True))
+                self._reduce(s, e)
         return hook
+
+    def _reduce(self, s, e):
+        if self.comm is not None:
+            self.comm.all_reduce_(self.flat.grads[s:e])
+        else:
+            self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Wait for the step's all-reduces (any bucket whose hooks did not all fire is reduced now)."""
@@ -168,10 +229,11 @@ class GradSync:
         if self.world > 1:
             for b, (s, e) in enumerate(self.buckets):
                 if not self._reduced[b]:
-                    self._work.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                                      async_op=True))
+                    self._reduce(s, e)
             for w in self._work:
                 w.wait()
+            if self.comm is not None:
+                self.comm.wait()
         self._work = []
         self._ready = [0] * len(self.buckets)
         self._reduced = [False] * len(self.buckets)

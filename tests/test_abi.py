@@ -57,3 +57,16 @@ def test_code_object_is_gfx950_only(built):
     data = open(built.LIB_PATH, "rb").read()
     targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", data))
     assert targets == {b"gfx950"}, targets
+
+
+def test_rccl_library_exports_every_symbol_of_its_header(built):
+    """include/dvslam_rccl.h <-> deep_visual_slam_amd/_rccl.py <-> libdvslam_rccl.so (no collective is called)."""
+    from deep_visual_slam_amd import _rccl
+    src = open(os.path.join(ROOT, "include", "dvslam_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(dvs_[a-z0-9_]+)\s*\(", src)))
+    assert names == _rccl.exported_symbols()
+    l = _rccl.lib()
+    for n in names:
+        assert hasattr(l, n), n
+    assert l.dvs_allreduce_run(None, None, 0, None) < 0 and b"null" in l.dvs_rccl_last_error()

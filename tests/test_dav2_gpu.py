@@ -1,7 +1,8 @@
 """GPU parity of the Depth-Anything-V2 ViT-S path (a14 / BASELINE.json configs[4]; csrc/vit.hip + the implicit-GEMM engine
 through deep_visual_slam_amd.depth_anything_v2) against reference-generated goldens (encoder) and the CPU oracle (whole net).
 
-fp32 tolerances: 12 transformer blocks deep with O(1) activations -> tokens rel-L2 1e-4 (measured in the report line); the
+fp32 tolerances: 12 transformer blocks deep with O(1) activations -> tokens and depth rel-L2 2e-5 (measured 3e-7 .. 8e-7,
+profiles/r02_dav2_gpu_tests.log); the
 kernels themselves (attention, LayerNorm, resize, deconv scatter) are checked against torch at 2e-5 of the tensor max."""
 import numpy as np
 import pytest
@@ -101,7 +102,7 @@ def test_dinov2_encoder_vs_reference_goldens(gpu_device, dav2):
     for i, (tok, cls) in enumerate(outs):
         e = rel(tok, rec["small/tok%d" % i])
         print("dinov2 84x112 tap %d rel-L2 %.2e" % (i, e))
-        assert tok.shape == rec["small/tok%d" % i].shape and e < 1e-4 and rel(cls, rec["small/cls%d" % i]) < 1e-4
+        assert tok.shape == rec["small/tok%d" % i].shape and e < 2e-5 and rel(cls, rec["small/cls%d" % i]) < 2e-5
     g = torch.Generator().manual_seed(1)
     torch.randn(2, 3, 84, 112, generator=g)
     x = torch.randn(1, 3, 518, 518, generator=g)
@@ -111,7 +112,7 @@ def test_dinov2_encoder_vs_reference_goldens(gpu_device, dav2):
         assert tok.shape == (1, 1369, 384) and cls.shape == (1, 384)
         e = rel(tok[0, ::37, ::7], rec["full/tok%d#sample" % i])
         print("dinov2 518x518 tap %d sample rel-L2 %.2e" % (i, e))
-        assert e < 1e-4 and rel(cls, rec["full/cls%d" % i]) < 1e-4
+        assert e < 2e-5 and rel(cls, rec["full/cls%d" % i]) < 2e-5
         t = tok.double().cpu().numpy()
         assert abs((t * t).sum() - rec["full/tok%d#sq" % i]) < 2e-4 * rec["full/tok%d#sq" % i]
 
@@ -131,7 +132,7 @@ def test_depth_anything_forward_vs_oracle(gpu_device, dav2, B, H, W):
     assert out.shape == (B, H, W)
     e = rel(out, ref)
     print("depth_anything_v2 %dx%d rel-L2 %.2e max-rel %.2e" % (H, W, e, relmax(out, ref)))
-    assert e < 2e-4
+    assert e < 2e-5                               # measured 3e-7 .. 5e-7
     assert disp[("disp", 0)].shape == (B, 1, H, W) and disp[("disp", 1)].shape == (B, 1, H // 2, W // 2)
     assert float(disp[("disp", 0)].min()) >= 0.0 and float(disp[("disp", 0)].max()) <= 1.0
 

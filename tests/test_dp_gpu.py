@@ -93,3 +93,30 @@ def test_two_ranks_on_one_gpu_reduce_identical_arenas(gpu_device):
     per_bucket = [(float(np.linalg.norm(got[0][2][0][s:e] - ref[s:e]) / (np.linalg.norm(ref[s:e]) + 1e-30)), s, e)
                   for s, e in got[0][4]]
     assert err < 2e-2, (err, sorted(per_bucket, reverse=True)[:6], float(np.linalg.norm(got[0][2][0])), float(np.linalg.norm(ref)))
+
+
+def test_direct_rccl_allreduce_single_rank(gpu_device):
+    """include/dvslam_rccl.h on the GPU: a one-rank communicator (what this one-GPU box can hold; the 8-GPU run is the
+    driver's): unique id, init, the sum all-reduce on the communicator's own stream ordered behind the producer stream,
+    wait, destroy.  With one rank the sum is the identity."""
+    from deep_visual_slam_amd import dp
+    comm = dp.RcclComm(gpu_device)
+    assert comm.world == 1 and comm.rank == 0 and comm.stream.cuda_stream != torch.cuda.current_stream().cuda_stream
+    x = torch.arange(1 << 20, device=gpu_device, dtype=torch.float32)
+    y = x * 2.0                                     # produced on the current stream; the all-reduce must wait for it
+    comm.all_reduce_(y)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(y, x * 2.0)
+    # as GradSync uses it: buckets of the arena reduced from hooks, finish() waits for the communicator's stream
+    p = torch.nn.Parameter(torch.randn(1000, device=gpu_device))
+    flat = dp.FlatParams([("p", p)])
+    sync = dp.GradSync(flat, comm=comm)
+    flat.grads.fill_(3.0)
+    sync._reduce(0, flat.numel)
+    sync.world = 2                                  # exercise finish()'s communicator wait
+    sync._reduced = [True] * len(sync.buckets)
+    sync.finish()
+    torch.cuda.synchronize()
+    assert float(flat.grads.min()) == 3.0 and float(flat.grads.max()) == 3.0
+    comm.close()
