@@ -102,6 +102,7 @@ _SIGNATURES = {
     "dvs_smooth_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dvs_smooth_fwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
     "dvs_smooth_bwd": (C.c_int, [_vp] * 4 + [C.c_int] * 4 + [_vp]),
+    "dvs_resample_u8": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_u8_to_f32_planar": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_color_jitter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dvs_color_jitter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

@@ -151,6 +151,40 @@ __global__ __launch_bounds__(NT) void color_jitter_kernel(float* __restrict__ im
     }
 }
 
+
+// ---- PIL Image.resize(..., Image.BILINEAR) on uint8 RGB frames (vo/dataset/common.py:38-44), bit exact -------------------
+// Pillow resamples in two passes (horizontal, then vertical), each with per-output-pixel integer coefficients
+// (22 fractional bits, the triangle filter stretched by the scale factor when shrinking = antialiasing) and each rounding to
+// uint8: out = clip8((2^21 + sum_k in[xmin + k] * coef[k]) >> 22).  The coefficient tables are built on the host exactly
+// as Pillow's precompute_coeffs / normalize_coeffs_8bpc do (input_pipeline.pil_bilinear_tables, double precision); the
+// kernel is the integer part.  One lane per output byte; `axis` 0: along x (pixels = rows * out_n), 1: along y.
+__global__ __launch_bounds__(NT) void resample_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                         const int* __restrict__ bounds, const int* __restrict__ coef, int ksize,
+                                                         int N, int in_h, int in_w, int out_h, int out_w, int axis) {
+    const size_t n = (size_t)N * out_h * out_w * 3;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % 3);
+        size_t t = i / 3;
+        const int x = (int)(t % out_w);
+        t /= out_w;
+        const int y = (int)(t % out_h), b = (int)(t / out_h);
+        const int o = axis ? y : x;
+        const int lo = bounds[2 * o], cnt = bounds[2 * o + 1];
+        const int* k = coef + (size_t)o * ksize;
+        int acc = 1 << 21;
+        const unsigned char* base = src + (size_t)b * in_h * in_w * 3 + c;
+        if (axis == 0) {
+            const unsigned char* row = base + (size_t)y * in_w * 3;
+            for (int j = 0; j < cnt; ++j) acc += (int)row[(size_t)(lo + j) * 3] * k[j];
+        } else {
+            const unsigned char* col = base + (size_t)x * 3;
+            for (int j = 0; j < cnt; ++j) acc += (int)col[(size_t)(lo + j) * in_w * 3] * k[j];
+        }
+        acc >>= 22;
+        dst[i] = (unsigned char)min(max(acc, 0), 255);
+    }
+}
+
 inline int jitter_blocks(int HW) {
     int b = (HW + NT * 8 - 1) / (NT * 8);
     return b < 1 ? 1 : (b > 256 ? 256 : b);      // <= NT partial sums per image (phase 1 adds them with one pass)
@@ -185,6 +219,20 @@ int dvs_color_jitter(float* images, const void* records, float* workspace, int N
     hipLaunchKernelGGL(color_jitter_kernel, dim3(blocks, N), dim3(NT), 0, st, images, recs, workspace, HW, 0);
     hipLaunchKernelGGL(color_jitter_kernel, dim3(blocks, N), dim3(NT), 0, st, images, recs, workspace, HW, 1);
     return dvs::check_launch("dvs_color_jitter");
+}
+
+int dvs_resample_u8(const unsigned char* src, unsigned char* dst, const int* bounds, const int* coef, int ksize, int N, int in_h,
+                    int in_w, int out_h, int out_w, int axis, void* stream) {
+    DVS_REQUIRE(src && dst && bounds && coef && ksize > 0 && N > 0 && in_h > 0 && in_w > 0 && out_h > 0 && out_w > 0 &&
+                    (axis == 0 || axis == 1),
+                "dvs_resample_u8: bad argument");
+    DVS_REQUIRE(axis == 0 ? in_h == out_h : in_w == out_w, "dvs_resample_u8: one axis per pass (axis 0 keeps the height, axis 1 the width)");
+    const size_t n = (size_t)N * out_h * out_w * 3;
+    size_t blocks = (n + NT - 1) / NT;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(resample_u8_kernel, dim3((unsigned)blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), src, dst, bounds,
+                       coef, ksize, N, in_h, in_w, out_h, out_w, axis);
+    return dvs::check_launch("dvs_resample_u8");
 }
 
 }  // extern "C"

@@ -46,6 +46,63 @@ class JitterParams:
         return np.repeat(rec, frames_per_sample, 0)
 
 
+def pil_bilinear_tables(in_size, out_size):
+    """(bounds int32 [out,2], coef int32 [out,ksize]) of one axis of PIL's Image.resize(..., Image.BILINEAR): the triangle
+    filter stretched by the scale factor when shrinking (Pillow's precompute_coeffs), normalised, converted to 22-bit
+    integers with round-half-away (normalize_coeffs_8bpc).  Host side, double precision, as Pillow computes them."""
+    import math
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        xmin = max(xmin, 0)
+        xmax = int(center + support + 0.5)
+        xmax = min(xmax, in_size) - xmin
+        w = []
+        for x in range(xmax):
+            v = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - v if v < 1.0 else 0.0)
+        ww = sum(w)
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            coef[xx, x] = int(-0.5 + k * (1 << 22)) if k < 0 else int(0.5 + k * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef
+
+
+_resize_tables = {}
+
+
+def resize_u8(frames_u8, out_h, out_w):
+    """PIL `img.resize((out_w, out_h), Image.BILINEAR)` of uint8 GPU frames [N,h,w,3] (vo/dataset/common.py:38-44), bit exact:
+    horizontal pass, then vertical pass, each rounding to uint8 (an axis whose size does not change is skipped)."""
+    if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.shape[-1] != 3:
+        raise _lib.DvsError("resize_u8: uint8 GPU tensor [N,h,w,3] expected")
+    x = frames_u8.contiguous()
+    N, h, w, _ = x.shape
+    l = _lib.lib()
+    for axis, (n_in, n_out) in ((0, (w, out_w)), (1, (h, out_h))):
+        if n_in == n_out:
+            continue
+        key = (n_in, n_out, x.device)
+        if key not in _resize_tables:
+            b, c = pil_bilinear_tables(n_in, n_out)
+            _resize_tables[key] = (torch.from_numpy(b).to(x.device), torch.from_numpy(c).to(x.device))
+        b, c = _resize_tables[key]
+        cur_h, cur_w = x.shape[1], x.shape[2]
+        oh, ow = (cur_h, out_w) if axis == 0 else (out_h, cur_w)
+        y = torch.empty(N, oh, ow, 3, device=x.device, dtype=torch.uint8)
+        check(l.dvs_resample_u8(ptr(x), ptr(y), ptr(b), ptr(c), c.shape[1], N, cur_h, cur_w, oh, ow, axis, _lib.stream()), "dvs_resample_u8")
+        x = y
+    return x
+
+
 def u8_to_f32_planar(frames_u8, bgr=False, out=None):
     """[N,H,W,3] uint8 -> [N,3,H,W] fp32 in [0,1] (ToTensor; bgr=True also swaps to RGB)."""
     if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8:
@@ -91,10 +148,16 @@ def intrinsics_pyramid(K, h, w, num_scales=4):
     return out
 
 
-def make_sample(frames_u8, K, records=None, bgr=False):
-    """GPU sample dict of the reference's schema from uint8 frames [B,3,H,W,3] already on the device."""
+def make_sample(frames_u8, K, records=None, bgr=False, image_size=None):
+    """GPU sample dict of the reference's schema from uint8 frames [B,3,h,w,3] already on the device; image_size = (H, W)
+    resizes them first as the reference's loader does (PIL bilinear, common.py:38-44; K is in pixels of the RESIZED image,
+    as the reference's intrinsics are)."""
     B, F, H, W, _ = frames_u8.shape
-    imgs = u8_to_f32_planar(frames_u8.view(B * F, H, W, 3), bgr=bgr)
+    flat = frames_u8.view(B * F, H, W, 3)
+    if image_size is not None and tuple(image_size) != (H, W):
+        H, W = image_size
+        flat = resize_u8(flat, H, W)
+    imgs = u8_to_f32_planar(flat, bgr=bgr)
     if records is not None:
         color_jitter_(imgs, records)
     imgs = imgs.view(B, F, 3, H, W)
@@ -111,8 +174,9 @@ class Prefetcher:
     handed out with an event the consumer's stream waits on -- the training step never waits for PCIe or for the
     augmentation unless the loader itself is late."""
 
-    def __init__(self, batches, device, augment=True, seed=0, bgr=False):
+    def __init__(self, batches, device, augment=True, seed=0, bgr=False, image_size=None):
         self.batches, self.device, self.augment, self.bgr = batches, torch.device(device), augment, bgr
+        self.image_size = image_size
         self.rng = np.random.default_rng(seed)
         self.stream = torch.cuda.Stream(device=self.device)
         self._pinned = [None, None]
@@ -135,7 +199,7 @@ class Prefetcher:
         with torch.cuda.stream(self.stream):
             dev = pin[0].to(self.device, non_blocking=True)
             pin[1].record(self.stream)
-            sample = make_sample(dev, batch["K"], rec, bgr=self.bgr)
+            sample = make_sample(dev, batch["K"], rec, bgr=self.bgr, image_size=self.image_size)
             ready = torch.cuda.Event()
             ready.record(self.stream)
         return sample, ready, dev

@@ -365,7 +365,14 @@ int dvs_depth_loss_bwd(const dvs_depth_loss_cfg* cfg, const float* const* pred_d
  *       in [-0.5, 0.5]).  Images that share a record's values get the same jitter (the reference jitters the three frames
  *       of a sample together); the contrast step's mean gray level is per image.  workspace: dvs_color_jitter_workspace
  *       bytes.
- * ------------------------------------------------------------------------------------------- */
+ *   dvs_resample_u8: one pass of PIL's Image.resize(size, Image.BILINEAR) on uint8 frames [N,h,w,3] (common.py:38-44:
+ *       antialiased triangle filter, 22-bit integer coefficients, uint8 rounding after each pass) -- bit exact.  axis 0
+ *       resamples along x ([N,h,in_w,3] -> [N,h,out_w,3]), axis 1 along y; bounds [out_n][2] = (first input index, tap
+ *       count), coef [out_n][ksize] integer taps, both built on the host exactly as Pillow does
+ *       (input_pipeline.pil_bilinear_tables).  A full resize = the x pass, then the y pass.
+ */
+int dvs_resample_u8(const unsigned char* src, unsigned char* dst, const int* bounds, const int* coef, int ksize, int N, int in_h,
+                    int in_w, int out_h, int out_w, int axis, void* stream);
 int dvs_u8_to_f32_planar(const unsigned char* src, float* dst, int N, int H, int W, int bgr, void* stream);
 size_t dvs_color_jitter_workspace(int N, int H, int W);
 int dvs_color_jitter(float* images, const void* records, float* workspace, int N, int H, int W, void* stream);

@@ -13,6 +13,46 @@ import numpy as np
 import torch
 
 
+def pil_resize_bilinear(img_u8, out_h, out_w):
+    """PIL's Image.resize((out_w, out_h), Image.BILINEAR) restated on a uint8 array [h,w,3] (Pillow's Resample.c:
+    precompute_coeffs + normalize_coeffs_8bpc + the horizontal, then the vertical 8-bit pass, each rounding to uint8).
+    PINNED by fixtures produced with Pillow itself (tests/golden/make_golden_pipeline.py -> pil_resize_*.npz)."""
+    import math
+
+    def tables(n_in, n_out):
+        scale = n_in / n_out
+        fs = max(scale, 1.0)
+        support = fs
+        ksize = int(math.ceil(support)) * 2 + 1
+        out = []
+        for xx in range(n_out):
+            center = (xx + 0.5) * scale
+            xmin = max(int(center - support + 0.5), 0)
+            xmax = min(int(center + support + 0.5), n_in) - xmin
+            w = [max(0.0, 1.0 - abs((x + xmin - center + 0.5) / fs)) for x in range(xmax)]
+            ww = sum(w)
+            k = [(v / ww if ww != 0.0 else v) for v in w]
+            out.append((xmin, [int(0.5 + v * (1 << 22)) for v in k]))
+        return out
+
+    def one_pass(a, n_out, axis):
+        a = np.moveaxis(a, axis, 0).astype(np.int64)
+        res = np.empty((n_out,) + a.shape[1:], dtype=np.uint8)
+        for o, (lo, ks) in enumerate(tables(a.shape[0], n_out)):
+            acc = np.full(a.shape[1:], 1 << 21, dtype=np.int64)
+            for j, kv in enumerate(ks):
+                acc += a[lo + j] * kv
+            res[o] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+        return np.moveaxis(res, 0, axis)
+
+    a = np.asarray(img_u8)
+    if a.shape[1] != out_w:
+        a = one_pass(a, out_w, 1)
+    if a.shape[0] != out_h:
+        a = one_pass(a, out_h, 0)
+    return a
+
+
 def to_tensor(frames_u8):
     """[N,H,W,3] uint8 (numpy / tensor) -> [N,3,H,W] fp32 in [0,1]."""
     t = torch.as_tensor(np.asarray(frames_u8))

@@ -249,3 +249,20 @@ def test_dpt_blocks_oracle_matches_reference():
     close(OD.fusion_block(sd, "fb.", a), rec["fuse1_x2"], atol=1e-5, rtol=1e-5)
     close(OD.residual_conv_unit(a, sd, "fb.resConfUnit2."), rec["rcu"], atol=1e-5, rtol=1e-5)
     close(torch.nn.functional.conv2d(torch.from_numpy(rec["l1_in"]), sd["l1.weight"], None, 1, 1), rec["l1_out"], atol=1e-5, rtol=1e-5)
+
+
+def test_pil_bilinear_resize_restatement_is_bit_exact():
+    """oracle/input_pipeline.pil_resize_bilinear against Pillow's own Image.resize(..., BILINEAR) outputs
+    (tests/golden/make_golden_pipeline.py), and the product's host-side coefficient tables against the oracle's."""
+    from oracle import input_pipeline as OI
+    rec = load_golden("pil_resize_bilinear.npz")
+    i = 0
+    while "in%d" % i in rec:
+        a, b = rec["in%d" % i], rec["out%d" % i]
+        assert np.array_equal(OI.pil_resize_bilinear(a, b.shape[0], b.shape[1]), b), i
+        i += 1
+    assert i == 6
+    from deep_visual_slam_amd.input_pipeline import pil_bilinear_tables
+    bounds, coef = pil_bilinear_tables(160, 64)
+    assert bounds.shape == (64, 2) and coef.shape[0] == 64 and (coef.sum(1) > 0).all()
+    assert abs(int(coef[10].sum()) - (1 << 22)) <= coef.shape[1]                 # taps sum to one (up to rounding)

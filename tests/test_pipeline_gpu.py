@@ -22,6 +22,30 @@ def test_u8_to_f32_planar_is_to_tensor(gpu_device):
         assert torch.equal(bgr.cpu(), got.cpu().flip(1))
 
 
+def test_pil_bilinear_resize_is_bit_exact(gpu_device):
+    """img.resize((W, H), Image.BILINEAR) of the reference's loader (vo/dataset/common.py:38-44) on the GPU, against outputs
+    of Pillow itself (tests/golden/pil_resize_bilinear.npz): shrinking (antialiased), enlarging, one axis only -- every byte."""
+    from conftest import load_golden
+    from deep_visual_slam_amd.input_pipeline import make_sample, resize_u8
+    rec = load_golden("pil_resize_bilinear.npz")
+    i = 0
+    while "in%d" % i in rec:
+        a, b = rec["in%d" % i], rec["out%d" % i]
+        x = torch.from_numpy(np.stack([a, a[::-1].copy()])).to(gpu_device)          # a batch of two
+        got = resize_u8(x, b.shape[0], b.shape[1]).cpu().numpy()
+        assert got.shape == (2,) + b.shape and np.array_equal(got[0], b), i
+        i += 1
+    assert i == 6
+    # through make_sample: frames arrive at another size than the training resolution
+    a, b = rec["in4"], rec["out4"]                                                   # 120x160 -> 48x64
+    frames = torch.from_numpy(np.stack([a, a, a])[None]).to(gpu_device)
+    K = np.eye(4, dtype=np.float32)[None]
+    sample = make_sample(frames, K, image_size=(48, 64))
+    ref = torch.from_numpy(b).permute(2, 0, 1).float() / 255.0
+    assert sample[("target_image", 0)].shape == (1, 3, 48, 64)
+    assert float((sample[("target_image", 0)][0].cpu() - ref).abs().max()) <= 6e-8
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_color_jitter_matches_oracle(gpu_device, seed):
     """ColorJitter(0.3, 0.3, 0.3, 0.2) on the three frames of each sample (common.py:31-37,79-81): every permutation
