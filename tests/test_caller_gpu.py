@@ -248,3 +248,53 @@ def test_eval_mode_with_autograd_is_differentiable_and_uses_running_stats(gpu_de
     for n in ("encoder.encoder.layer3.0.bn2.weight", "encoder.encoder.layer2.0.downsample.1.bias", "encoder.encoder.conv1.weight"):
         assert rel(dict(dn.named_parameters())[n].grad, cd[n].grad) < 2e-3 + 2 * flip, n
     assert rel(dict(dn.named_parameters())["decoder.9.conv.conv.weight"].grad, cd["decoder.9.conv.conv.weight"].grad) < 1e-4
+
+
+def test_one_line_optimizer_swap_keeps_the_caller_sequence(gpu_device):
+    """INTEGRATION.md: replace only the optimiser construction of vo/train.py:114-117 by dp.FusedAdam over a FlatParams arena;
+    `optimizer.zero_grad(set_to_none=True)`, `backward()`, `optimizer.step()`, the scheduler and the `.cpu()` calls stay.
+    Two steps against the same sequence with stock torch.optim.Adam on identical weights and inputs."""
+    from deep_visual_slam_amd import dp, gradsink, synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    sample = synth.parity_sample(B, H, W)
+    g = torch.Generator().manual_seed(7)
+    noises = [torch.stack([torch.randn(B, 2, H, W, generator=g) for _ in range(4)]).to(gpu_device) for _ in range(2)]
+    results = []
+    for fused in (False, True):
+        gradsink.reset_streams()
+        dn, pn, _, _ = _nets(gpu_device, seed=0)
+        dn.train()
+        pn.train()
+        if fused:
+            flat = dp.FlatParams(dp.trainable_parameters(dn, pn))
+            optimizer = dp.FusedAdam(flat, lr=LR, params=list(dn.parameters()) + list(pn.parameters()))
+        else:
+            optimizer = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), lr=LR)
+        scheduler = torch.optim.lr_scheduler.PolynomialLR(optimizer, total_iters=30, power=0.9)
+        learner = MonodepthTrainer(dn, pn, _cfg(), gpu_device)
+        seen = []
+        for it in range(2):
+            learner._noise = noises[it]
+            optimizer.zero_grad(set_to_none=True)
+            outputs, losses = learner.process_batch(dict(sample))
+            total_loss = losses["loss"]
+            total_loss.backward()
+            optimizer.step()
+            for key in losses:
+                losses[key] = losses[key].detach().cpu()
+            seen.append({k: float(v) for k, v in losses.items()})
+        scheduler.step()
+        torch.cuda.synchronize()
+        results.append((seen, {k: v.detach().cpu().clone() for k, v in list(dn.named_parameters()) + list(pn.named_parameters())},
+                        optimizer.param_groups[0]["lr"]))
+    (l_a, w_a, lr_a), (l_b, w_b, lr_b) = results
+    assert lr_a == lr_b and lr_a < LR
+    for k in l_a[0]:
+        assert abs(l_a[0][k] - l_b[0][k]) < 1e-6 * abs(l_a[0][k])              # same weights, same kernels
+        assert abs(l_a[1][k] - l_b[1][k]) < 1e-3 * abs(l_a[1][k])              # after one sign-like Adam update
+    n_bad = n_all = 0
+    for k in w_a:
+        d = (w_a[k] - w_b[k]).abs()
+        n_bad += int((d > 0.2 * LR).sum())
+        n_all += d.numel()
+    assert n_bad / n_all < 0.02, n_bad / n_all
