@@ -78,6 +78,8 @@ _SIGNATURES = {
     "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),
     "dvs_bn_bwd_apply": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_last_error": (C.c_char_p, []),
+    "dvs_set_deterministic": (C.c_int, [C.c_int]),
+    "dvs_get_deterministic": (C.c_int, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),
     "dvs_profile_enable": (C.c_int, [C.c_int]),
@@ -141,6 +143,22 @@ def lib():
             raise DvsError("libdvslam_hip.so ABI %d != binding ABI %d; rebuild" % (l.dvs_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
+
+
+_deterministic = os.environ.get("DVS_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(on):
+    """Deterministic forward pass (include/dvslam.h: dvs_set_deterministic): a test / debugging mode, ~10 % slower."""
+    global _deterministic
+    _deterministic = bool(on)
+    check(lib().dvs_set_deterministic(int(_deterministic)), "dvs_set_deterministic")
+
+
+def deterministic():
+    if _deterministic and _lib is not None and not _lib.dvs_get_deterministic():
+        _lib.dvs_set_deterministic(1)           # DVS_DETERMINISTIC=1 from the environment: tell the library once it is loaded
+    return _deterministic
 
 
 def check(rc, what):

@@ -114,6 +114,23 @@ class _BNAct(torch.autograd.Function):
         return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None, None
 
 
+def channel_stats(y, groups=1):
+    """[G][2][C] per-channel sum / sum of squares of y (NHWC) in a fixed summation order: the deterministic stand-in for the
+    convolution's atomic statistics epilogue (dvs_set_deterministic).  It is the BatchNorm backward's reduction kernel with
+    (dz, mean, invstd) = (y, 0, 1): sum g = sum y, sum g * (y - 0) * 1 = sum y^2."""
+    B, C, H, W = y.shape
+    M = B * H * W // groups
+    y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
+    l = _lib.lib()
+    table = torch.zeros(groups, 4, C, device=y.device, dtype=torch.float32)        # rows 2, 3: mean = 0, invstd = 1
+    table[:, 3].fill_(1.0)
+    sums = torch.zeros(groups, 2, C, device=y.device, dtype=torch.float32)
+    ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, groups) // 4, device=y.device, dtype=torch.float32)
+    check(l.dvs_bn_bwd_reduce(y.data_ptr(), None, y.data_ptr(), table[0, 2].data_ptr(), table[0, 3].data_ptr(), None,
+                              sums.data_ptr(), ptr(ws), M, C, groups, _lib.stream()), "dvs_bn_bwd_reduce")
+    return sums if groups > 1 else sums[0]
+
+
 def supported_c(C, bn):
     """The fused kernels cover training-mode affine BatchNorm with C/4 dividing 256 (C = 16 ... 1024)."""
     return bn.training and bn.affine and C % 4 == 0 and (256 % (C // 4) == 0)

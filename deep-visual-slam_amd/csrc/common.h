@@ -67,6 +67,11 @@ struct ProfScope {
     }
 };
 
+// dvs_set_deterministic(1): the FORWARD pass repeats bit for bit from run to run -- no split-K forward / data-gradient
+// launches (float atomics on the output), BatchNorm partial sums added in one fixed order -- so that two runs take the same
+// ReLU / maxpool branches and their gradients differ by smooth rounding noise only.
+bool deterministic();
+
 constexpr int kWave = 64;  // gfx950 wavefront
 
 // 64-lane butterfly sum; every lane ends with the total.

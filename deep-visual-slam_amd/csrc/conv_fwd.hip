@@ -467,7 +467,7 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
         // gradients of layer 4).
         static const bool splitk = [] { const char* e = getenv("DVS_CONV_SPLITK"); return !(e && e[0] == '0'); }();
         const int tiles = grid.x * grid.y, nC = p.s.Cin / BK;
-        if (splitk && !p.stats && tiles < 200 && nC >= 2 && (p.s.Cout & 3) == 0) {
+        if (splitk && !dvs::deterministic() && !p.stats && tiles < 200 && nC >= 2 && (p.s.Cout & 3) == 0) {
             int want = min(nC, (256 + tiles - 1) / tiles);
             const int per = (nC + want - 1) / want;
             q.ksplit = (nC + per - 1) / per;

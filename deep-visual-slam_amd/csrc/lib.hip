@@ -52,6 +52,12 @@ void drain_locked(int slot) {
 
 bool prof_enabled() { return g_on.load(std::memory_order_relaxed); }
 
+namespace {
+std::atomic<bool> g_deterministic{false};
+}
+bool deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
+void set_deterministic(bool on) { g_deterministic.store(on); }
+
 void prof_begin(int, hipStream_t st, hipEvent_t* start) {
     if (hipEventCreate(start) != hipSuccess) {
         *start = nullptr;
@@ -116,6 +122,13 @@ int dvs_profile_read(int slot, double* total_ms, long* launches) {
 }
 
 const char* dvs_last_error(void) { return dvs::err_buf(); }
+
+int dvs_set_deterministic(int on) {
+    dvs::set_deterministic(on != 0);
+    return DVS_OK;
+}
+
+int dvs_get_deterministic(void) { return dvs::deterministic() ? 1 : 0; }
 
 int dvs_abi_version(void) { return 4; }
 

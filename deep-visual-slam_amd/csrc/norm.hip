@@ -395,7 +395,8 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
                            invstd, du, workspace, (int)M, C, rpb);
     }
-    const int slices = blocks >= 64 ? 32 : 1, rps = (blocks + slices - 1) / slices;
+    // one slice = one ordered sum per address (deterministic mode); 32 slices = 32 float atomics per address
+    const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
     hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices, groups), dim3(NT), 0, st, workspace, sums, blocks,
                        2 * C, rps);
     return dvs::check_launch("dvs_bn_bwd_reduce");

@@ -150,6 +150,14 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
         raise _lib.DvsError("conv_bn_act: the fused BatchNorm kernels cover affine BatchNorm2d with C % 4 == 0 and C/4 "
                             "dividing 256 (got C = %d)" % weight.shape[0])
     G = _batch_groups
+    if _lib.deterministic():
+        # deterministic forward: no atomic statistics epilogue -- the batch statistics come from an ordered reduction pass
+        y = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm)
+        st = _bn.channel_stats(y.detach(), G)
+        if res is not None:
+            yd = _conv.conv2d(residual, res[0], None, res[2], 0)
+            return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=_bn.channel_stats(yd.detach(), G), groups=G)
+        return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
     y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G)
     if res is not None:
         yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G)

@@ -46,6 +46,14 @@ int dvs_abi_version(void);
 /* Name of the code-object architecture the kernels were compiled for ("gfx950"). */
 const char* dvs_arch(void);
 
+/* Deterministic forward (test / debugging mode, off by default): with on != 0 no forward or data-gradient launch is split
+ * over K with float atomics and the BatchNorm partial sums are added in one fixed order, so a forward pass repeats bit
+ * for bit and two runs take the same ReLU / maxpool branches (their gradients then differ by smooth rounding noise only;
+ * DESIGN.md section 6).  The BatchNorm batch statistics must then come from dvs_bn_bwd_reduce(dz = y, z = NULL, y,
+ * mean = 0, invstd = 1) instead of the convolution's atomic statistics epilogue (the Python side does that). */
+int dvs_set_deterministic(int on);
+int dvs_get_deterministic(void);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around each main kernel (used by
  * bench.py for the roofline line; off by default).  dvs_profile_enable(1) clears the counters;
  * dvs_profile_read synchronises the recorded events of one slot and returns the accumulated

@@ -27,10 +27,11 @@ def _free_port():
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    from deep_visual_slam_amd import dp, gradsink, synth
+    from deep_visual_slam_amd import _lib, dp, gradsink, synth
     from deep_visual_slam_amd.depthnet import DepthNet
     from deep_visual_slam_amd.learner_new import MonodepthTrainer
     from deep_visual_slam_amd.posenet_single import PoseNet
+    _lib.set_deterministic(True)           # same ReLU branches in the local and the reduced pass: the sums can be compared tightly
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
@@ -87,12 +88,13 @@ def test_two_ranks_on_one_gpu_reduce_identical_arenas(gpu_device):
     for step in range(2):
         a, b = got[0][2][step], got[1][2][step]
         assert np.array_equal(a, b), "ranks disagree after the all-reduce: %d elements" % int((a != b).sum())
-    # the reduced arena is the sum of the two local gradients (atomics-order noise between two passes aside)
+    # the reduced arena is the sum of the two local gradients (deterministic forward: only the smooth rounding noise of the
+    # backward's float atomics separates the two passes; round 1 had to allow 2e-2 for flipped ReLU branches)
     ref = got[0][1].astype(np.float64) + got[1][1].astype(np.float64)
     err = np.linalg.norm(got[0][2][0] - ref) / np.linalg.norm(ref)
     per_bucket = [(float(np.linalg.norm(got[0][2][0][s:e] - ref[s:e]) / (np.linalg.norm(ref[s:e]) + 1e-30)), s, e)
                   for s, e in got[0][4]]
-    assert err < 2e-2, (err, sorted(per_bucket, reverse=True)[:6], float(np.linalg.norm(got[0][2][0])), float(np.linalg.norm(ref)))
+    assert err < 2e-4, (err, sorted(per_bucket, reverse=True)[:6], float(np.linalg.norm(got[0][2][0])), float(np.linalg.norm(ref)))
 
 
 def test_direct_rccl_allreduce_single_rank(gpu_device):

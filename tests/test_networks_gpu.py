@@ -104,7 +104,7 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
     on identical weights with sinks off (autograd's AccumulateGrad) must give the same arena up to the
     run-to-run noise of the atomics (measured between two sink-less runs), a second backward must accumulate
     (not overwrite), and every parameter's post-accumulate hook fires exactly once per backward."""
-    from deep_visual_slam_amd import dp, gradsink, synth
+    from deep_visual_slam_amd import _lib, dp, gradsink, synth
     from deep_visual_slam_amd.depthnet import DepthNet
     from deep_visual_slam_amd.learner_new import MonodepthTrainer
     from deep_visual_slam_amd.posenet_single import PoseNet
@@ -115,6 +115,36 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
     g = torch.Generator().manual_seed(11)
     noise = torch.stack([torch.randn(B, 2, H, W, generator=g) for _ in range(4)]).to(gpu_device)
     arenas, fired = [], None
+    # Deterministic forward (dvs_set_deterministic): every run takes the same ReLU / maxpool branches, so what is left
+    # between two runs is the smooth rounding noise of the backward's float atomics -- the comparison below can then be
+    # tight enough to see a lost or doubled contribution of ANY size (round 1 had to allow 4 x jitter + 5e-3).
+    _lib.set_deterministic(True)
+    try:
+        _sink_runs(gpu_device, cfg, sample, noise, arenas, B, H, W)
+    finally:
+        _lib.set_deterministic(False)
+    fired = arenas.pop()
+    (a1, a2, flat), (b1, b2, _), (s1, s2, _) = arenas
+    worst = (0.0, 0.0, "")
+    for ref, other, got in ((a1, b1, s1), (a2, b2, s2)):
+        for n, p, o in zip(flat.names, flat.tensors, flat.offsets):
+            r, q, t = (x[o:o + p.numel()].double() for x in (ref, other, got))
+            scale = float(r.norm()) + 1e-30
+            jitter, err = float((r - q).norm()) / scale, float((r - t).norm()) / scale
+            worst = max(worst, (err, jitter, n))
+            assert jitter <= 2e-4 and err <= 2e-4, (n, err, jitter)
+    print("worst sink-vs-autograd rel-L2 %.2e (run-to-run there %.2e) at %s" % worst)
+    assert float((s2 - 2 * s1).norm()) <= 2e-4 * float(s1.norm())
+    assert set(fired) == set(flat.names), sorted(set(flat.names) - set(fired))
+    assert all(v == 2 for v in fired.values()), {k: v for k, v in fired.items() if v != 2}
+
+
+def _sink_runs(gpu_device, cfg, sample, noise, arenas, B, H, W):
+    from deep_visual_slam_amd import dp, gradsink
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    fired = None
     for sinks in (False, False, True):
         torch.manual_seed(5)
         dn = DepthNet(18, pretrained=False).to(gpu_device).train()
@@ -133,24 +163,7 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
             if rep == 0:
                 first = flat.grads.clone()
         arenas.append((first, flat.grads.clone(), flat))
-    (a1, a2, flat), (b1, b2, _), (s1, s2, _) = arenas
-    worst = (0.0, 0.0, "")
-    for ref, other, got in ((a1, b1, s1), (a2, b2, s2)):
-        for n, p, o in zip(flat.names, flat.tensors, flat.offsets):
-            r, q, t = (x[o:o + p.numel()].double() for x in (ref, other, got))
-            scale = float(r.norm()) + 1e-30
-            jitter, err = float((r - q).norm()) / scale, float((r - t).norm()) / scale
-            worst = max(worst, (err, jitter, n))
-            # a sink bug (lost or doubled contribution) is an O(1) error; atomics-order noise, amplified by the
-            # tiny BatchNorm batches of this 96x128 case, reaches a few 1e-3 on single tensors
-            assert err <= 4 * jitter + 5e-3, (n, err, jitter)
-    print("worst sink-vs-autograd rel-L2 %.2e (run-to-run jitter there %.2e) at %s" % worst)
-    # the weights are the same in both passes (no optimiser step): 2nd arena == 2 x 1st up to that jitter
-    assert float((s2 - 2 * s1).norm()) <= 2e-2 * float(s1.norm())
-    # "gradient complete" hooks (what dp.GradSync builds its buckets on) fire once per backward for every
-    # parameter, sunk (the Functions return None) or not (conv1 of both encoders), used once or twice (PoseNet)
-    assert set(fired) == set(flat.names), sorted(set(flat.names) - set(fired))
-    assert all(v == 2 for v in fired.values()), {k: v for k, v in fired.items() if v != 2}
+    arenas.append(fired)
 
 
 def test_posenet_pairs_in_one_pass_equal_two_calls(gpu_device):
