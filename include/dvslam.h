@@ -273,8 +273,9 @@ typedef struct {
     float* partials;                 /* per-block partial sums */
     uint8_t* sel;                    /* [B,H,W] argmin of the 4-way min, 2 bits per scale */
     float* stats;                    /* [B,S,4] per-image sums {min-loss, disp_up, Gx, Gy}, followed by a per-image camera
-                                        table (inv_K[:3,:3], (K.T_-1)[:3,:], (K.T_+1)[:3,:]) the forward call writes
-                                        and the backward call reads: allocate dvs_chain_workspace's stats_bytes */
+                                        table (inv_K[:3,:3], (K.T_-1)[:3,:], (K.T_+1)[:3,:]) and RGBA-packed copies of the two
+                                        source frames (2*B*H*W*16 bytes) that the forward call writes and the backward call
+                                        reads: allocate dvs_chain_workspace's stats_bytes and keep it until the backward */
     /* outputs */
     float* losses;                   /* [S] losses["loss/s"] */
     /* optional materialised tensors of the reference's `outputs` dict (NULL = skip) */
