@@ -56,6 +56,7 @@ class FlatParams:
             self._view(self.params, p, o).copy_(p.data)
             p.data = self._view(self.params, p, o)
             p.grad = self._view(self.grads, p, o)
+            p._dvs_arena = True                  # MonodepthTrainer does not build an arena of its own over these
             if grad_sinks:
                 gradsink.attach(p, p.grad)
 

@@ -109,6 +109,22 @@ class MonodepthTrainer:
                             if use_stream and torch.device(self.device).type == "cuda" else None)
         ops.chain_aux_stream = self.pose_stream          # loss-chain backward by scale (DVS_CHAIN_SPLIT=1) runs its coarse scales there
         self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]
+        # The unchanged caller (vo/train.py:114-117,173-199) builds a stock torch.optim.Adam over plain parameters and
+        # calls zero_grad(set_to_none=True) every step.  Unless told otherwise the trainer moves the two networks'
+        # parameters into one flat arena itself (dp.FlatParams: same Parameter objects, same values, `.data` / `.grad`
+        # become views), so that the weight-gradient, head and BatchNorm kernels can accumulate straight into the gradient
+        # arena on their side streams also for that caller; `process_batch` re-attaches and zeroes the gradient views after
+        # a set_to_none, and the loss chain's backward queues a join of the side streams at the end of the backward pass,
+        # so whoever reads `.grad` next (torch.optim, clip_grad_norm_) sees complete gradients.
+        self.arena = self._arena_packs = None
+        want_arena = tr.get("arena", os.environ.get("DVS_ARENA", "1") != "0")
+        if want_arena and torch.device(self.device).type == "cuda" and depth_net is not None and pose_net is not None:
+            from . import conv as _conv, dp
+            named = dp.trainable_parameters(depth_net, pose_net)
+            if named and all(p.is_cuda for _, p in named) and not any(getattr(p, "_dvs_arena", False) for _, p in named):
+                self.arena = dp.FlatParams(named)
+                self._arena_packs = _conv.PackedWeights(self.arena.tensors)
+                self._arena_versions = None
 
         # standalone operators kept as public attributes like the reference (learner_new.py:44-57)
         self.ssim = SSIM().to(self.device)
@@ -127,6 +143,8 @@ class MonodepthTrainer:
                 sample[key] = sample[key].to(self.device, non_blocking=True)
         gradsink.join()                                          # side-stream kernels of the previous step
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
+        if self.arena is not None and torch.is_grad_enabled():
+            self._arena_prepare()
         ops.chain_aux_stream = self.pose_stream                  # follows the attribute (bench.py switches it off to time kernels)
         if self.pose_stream is None:
             outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
@@ -147,6 +165,21 @@ class MonodepthTrainer:
             outputs.update(poses)
         losses = self._fused_losses(sample, outputs)
         return outputs, losses
+
+    def _arena_prepare(self):
+        """Start of a training step on the trainer-owned arena: gradients that the caller set to None are re-attached to
+        the (re-zeroed) gradient arena so the kernels can sink into them; the data-gradient weight packs are refreshed with
+        one launch when an optimiser has changed the weights since the last step."""
+        a = self.arena
+        if any(p.grad is None for p in a.tensors):
+            if all(p.grad is None for p in a.tensors):
+                a.grads.zero_()
+                a.reattach()
+            # a mixture (the caller dropped some gradients and kept others) is left alone: plain autograd accumulation
+        vers = sum(p._version for p in self._arena_packs.weights)
+        if vers != self._arena_versions:
+            self._arena_packs.repack()
+            self._arena_versions = vers
 
     def _predict_poses(self, sample):
         """learner_new.py:107-129."""

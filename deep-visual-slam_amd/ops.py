@@ -130,6 +130,15 @@ class _LossChain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_losses, *_unused):
+        # The chain is the first node of the step's backward pass: queue a join of the weight-gradient side streams for
+        # the END of this backward pass (the engine runs the callback in the thread that called backward(), on its
+        # current stream), so that whatever reads the sunk gradients next -- any optimiser, clip_grad_norm_ -- is ordered
+        # behind the kernels that produce them.
+        from . import gradsink as _gs
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_gs.join)
+        except Exception:
+            pass                                  # not inside an engine-driven backward (e.g. torch.autograd.functional)
         target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps = ctx.saved_tensors
         B, _, H, W = target.shape
         dev = target.device
