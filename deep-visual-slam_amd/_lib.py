@@ -108,7 +108,13 @@ _SIGNATURES = {
     "dvs_u8_to_f32_planar": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_color_jitter_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dvs_color_jitter": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
-    "dvs_attention_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_attention_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
+    "dvs_act_fwd": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "dvs_act_bwd_in": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "dvs_resize_bilinear_ac_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_deconv_unshuffle": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp]),
     "dvs_vit_patchify": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_vit_assemble": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

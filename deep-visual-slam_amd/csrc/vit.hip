@@ -37,6 +37,7 @@ struct AttnParams {
     float* out;                    // [B][N][heads*HD]
     int B, N, heads;
     float scale;
+    float* lse;                    // optional [B][heads][N]: log-sum-exp of each score row (kept for the backward)
 };
 
 __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
             l += w[v] * sL[v][q];
         }
         const float inv = 1.f / l;
+        if (p.lse && d0 == 0 && q0 + q < N) p.lse[((size_t)b * p.heads + head) * N + q0 + q] = m + __logf(l);
         if (q0 + q < N) {
             float* op = p.out + ((size_t)b * N + q0 + q) * C + (size_t)head * HD + d0;
             float res[8];
@@ -167,6 +169,228 @@ __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
             }
             *reinterpret_cast<f32x4*>(op) = f32x4{res[0], res[1], res[2], res[3]};
             *reinterpret_cast<f32x4*>(op + 4) = f32x4{res[4], res[5], res[6], res[7]};
+        }
+    }
+}
+
+
+// ---- attention backward -------------------------------------------------------------------------------------------------
+// With P = exp(S - lse), D_q = sum_d dO[q][d] O[q][d]:   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - D),
+// dQ = scale dS K,   dK = scale dS^T Q.   Two kernels in the forward's register layout, each recomputing S and dP for its
+// tiles (7 GEMM units against the forward's 2; no atomics):
+//   attention_bwd_dq_kernel   owns 32 queries (waves split the keys):  S^T = K Q^T and dP^T = V dO^T land key-major per
+//                             lane exactly like the forward's scores, dS^T feeds dQ^T += K^T dS^T as a B operand from its
+//                             registers;
+//   attention_bwd_dkv_kernel  owns 32 keys (waves split the queries):  S = Q K^T and dP = dO V^T land query-major per lane
+//                             (a lane holds 16 queries of one key), P and dS feed dV^T += dO^T P and dK^T += Q^T dS.
+struct AttnBwdParams {
+    const float* qkv;              // [B][N][3][heads][HD]
+    const float* d_out;            // [B][N][heads*HD]
+    const float* lse;              // [B][heads][N]
+    const float* delta;            // [B][heads][N]   D_q
+    float* d_qkv;                  // [B][N][3][heads][HD]
+    int B, N, heads;
+    float scale;
+};
+
+__global__ __launch_bounds__(NT) void attention_delta_kernel(const float* __restrict__ out, const float* __restrict__ d_out,
+                                                             float* __restrict__ delta, int B, int N, int heads) {
+    const size_t n = (size_t)B * N * heads;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int head = (int)(i % heads);
+        const size_t bq = i / heads;
+        const int q = (int)(bq % N), b = (int)(bq / N);
+        const f32x4* o = reinterpret_cast<const f32x4*>(out + (bq * heads + head) * HD);
+        const f32x4* g = reinterpret_cast<const f32x4*>(d_out + (bq * heads + head) * HD);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD / 4; ++e) {
+            const f32x4 a = o[e], c = g[e];
+            acc += (a[0] * c[0] + a[1] * c[1]) + (a[2] * c[2] + a[3] * c[3]);
+        }
+        delta[((size_t)b * heads + head) * N + q] = acc;
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void attention_bwd_dq_kernel(AttnBwdParams p) {
+    __shared__ float sO[4][HD][QT + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * QT, head = blockIdx.y, b = blockIdx.z;
+    const int N = p.N, C = p.heads * HD;
+    const size_t row = (size_t)3 * C;
+    const float* base = p.qkv + (size_t)b * N * row + (size_t)head * HD;
+    const float* Q = base, * K = base + C, * V = base + 2 * C;
+    const int qi = min(q0 + r, N - 1);
+    f32x4 qv[8], gv[8];
+    {
+        const float* qp = Q + (size_t)qi * row;
+        const float* gp = p.d_out + ((size_t)b * N + qi) * C + (size_t)head * HD;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            qv[j] = *reinterpret_cast<const f32x4*>(qp + 4 * (2 * j + h)) * p.scale;
+            gv[j] = *reinterpret_cast<const f32x4*>(gp + 4 * (2 * j + h));
+        }
+    }
+    const float Lq = p.lse[((size_t)b * p.heads + head) * N + qi], Dq = p.delta[((size_t)b * p.heads + head) * N + qi];
+    f32x16 a0, a1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+    const int ntiles = (N + KT - 1) / KT;
+    for (int t = wave; t < ntiles; t += 4) {
+        const int k0 = t * KT;
+        const int ki = min(k0 + r, N - 1);
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        {
+            const float* kp = K + (size_t)ki * row;
+            const float* vp = V + (size_t)ki * row;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * (2 * j + h));
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + 4 * (2 * j + h));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[u], qv[j][u], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[u], gv[j][u], dp, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const float pr = key < N ? __expf(s[i] - Lq) : 0.f;
+            s[i] = pr * (dp[i] - Dq);                      // dS^T for (key, my query)
+        }
+        // dQ^T[dim][query] += K^T[dim][key] dS^T[key][query]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kj = min(k0 + 8 * j + 4 * h + u, N - 1);
+                const float* kp = K + (size_t)kj * row;
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[r], s[4 * j + u], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[32 + r], s[4 * j + u], a1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sO[wave][d][r] = a0[i];
+        sO[wave][32 + d][r] = a1[i];
+    }
+    __syncthreads();
+    {
+        const int q = tid >> 3, d0 = (tid & 7) * 8;
+        if (q0 + q < N) {
+            float* op = p.d_qkv + ((size_t)b * N + q0 + q) * row + (size_t)head * HD + d0;
+            float res[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                res[e] = ((sO[0][d0 + e][q] + sO[1][d0 + e][q]) + (sO[2][d0 + e][q] + sO[3][d0 + e][q])) * p.scale;
+            *reinterpret_cast<f32x4*>(op) = f32x4{res[0], res[1], res[2], res[3]};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{res[4], res[5], res[6], res[7]};
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT, 1) void attention_bwd_dkv_kernel(AttnBwdParams p) {
+    __shared__ float sK[4][HD][QT + 1];
+    __shared__ float sV[4][HD][QT + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int k0 = blockIdx.x * KT, head = blockIdx.y, b = blockIdx.z;
+    const int N = p.N, C = p.heads * HD;
+    const size_t row = (size_t)3 * C;
+    const float* base = p.qkv + (size_t)b * N * row + (size_t)head * HD;
+    const float* Q = base, * K = base + C, * V = base + 2 * C;
+    const float* G = p.d_out + (size_t)b * N * C + (size_t)head * HD;          // dO rows, stride C
+    const float* lse = p.lse + ((size_t)b * p.heads + head) * N;
+    const float* dlt = p.delta + ((size_t)b * p.heads + head) * N;
+    // B operands: my key (column r), resident
+    f32x4 kv[8], vv[8];
+    {
+        const int ki = min(k0 + r, N - 1);
+        const float* kp = K + (size_t)ki * row;
+        const float* vp = V + (size_t)ki * row;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kv[j] = *reinterpret_cast<const f32x4*>(kp + 4 * (2 * j + h));
+            vv[j] = *reinterpret_cast<const f32x4*>(vp + 4 * (2 * j + h));
+        }
+    }
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
+    const int ntiles = (N + QT - 1) / QT;
+    for (int t = wave; t < ntiles; t += 4) {
+        const int q0 = t * QT;
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        {
+            const int qi = min(q0 + r, N - 1);
+            const float* qp = Q + (size_t)qi * row;
+            const float* gp = G + (size_t)qi * C;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + 4 * (2 * j + h)) * p.scale;
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(gp + 4 * (2 * j + h));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qq[u], kv[j][u], s, 0, 0, 0);       // S[query][key]
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gg[u], vv[j][u], dp, 0, 0, 0);     // dP[query][key]
+                }
+            }
+        }
+        // s[i] / dp[i]: query q0 + (i & 3) + 8 (i >> 2) + 4 h, my key
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int qc = min(q, N - 1);
+            const float pr = q < N ? __expf(s[i] - lse[qc]) : 0.f;
+            dp[i] = pr * (dp[i] - dlt[qc]);                 // dS
+            s[i] = pr;                                      // P
+        }
+        // dV^T[dim][key] += dO^T[dim][query] P[query][key];  dK^T[dim][key] += Q^T[dim][query] dS[query][key]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qj = min(q0 + 8 * j + 4 * h + u, N - 1);
+                const float* gp = G + (size_t)qj * C;
+                const float* qp = Q + (size_t)qj * row;
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[r], s[4 * j + u], dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[32 + r], s[4 * j + u], dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[r], dp[4 * j + u], dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[32 + r], dp[4 * j + u], dk1, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sK[wave][d][r] = dk0[i];
+        sK[wave][32 + d][r] = dk1[i];
+        sV[wave][d][r] = dv0[i];
+        sV[wave][32 + d][r] = dv1[i];
+    }
+    __syncthreads();
+    {
+        const int k = tid >> 3, d0 = (tid & 7) * 8;
+        if (k0 + k < N) {
+            float* okp = p.d_qkv + ((size_t)b * N + k0 + k) * row + C + (size_t)head * HD + d0;
+            float* ovp = okp + C;
+            float rk[8], rv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                rk[e] = ((sK[0][d0 + e][k] + sK[1][d0 + e][k]) + (sK[2][d0 + e][k] + sK[3][d0 + e][k])) * p.scale;
+                rv[e] = (sV[0][d0 + e][k] + sV[1][d0 + e][k]) + (sV[2][d0 + e][k] + sV[3][d0 + e][k]);
+            }
+            *reinterpret_cast<f32x4*>(okp) = f32x4{rk[0], rk[1], rk[2], rk[3]};
+            *reinterpret_cast<f32x4*>(okp + 4) = f32x4{rk[4], rk[5], rk[6], rk[7]};
+            *reinterpret_cast<f32x4*>(ovp) = f32x4{rv[0], rv[1], rv[2], rv[3]};
+            *reinterpret_cast<f32x4*>(ovp + 4) = f32x4{rv[4], rv[5], rv[6], rv[7]};
         }
     }
 }
@@ -294,6 +518,167 @@ __global__ __launch_bounds__(NT) void deconv_shuffle_kernel(const float* __restr
     }
 }
 
+
+// ---- LayerNorm backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; dgamma += sum_rows dy xhat, dbeta += sum_rows dy
+template <int VPL>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ dy, float* __restrict__ dx,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63, wrow = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), nw = gridDim.x * (NT / 64);
+    const int cv = C >> 2;
+    f32x4 ag[VPL], ab[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { ag[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int row = wrow; row < M; row += nw) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * C);
+        const f32x4* gr = reinterpret_cast<const f32x4*>(dy + (size_t)row * C);
+        f32x4 v[VPL], d[VPL];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cv ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            d[i] = c < cv ? gr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = dvs::wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[i][e] - mean;
+                    sq += t * t;
+                }
+            }
+        }
+        const float rstd = rsqrtf(dvs::wave_sum(sq) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cv) {
+                const f32x4 gg = reinterpret_cast<const f32x4*>(g)[c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[i][e] - mean) * rstd;
+                    ag[i][e] += d[i][e] * xh;
+                    ab[i][e] += d[i][e];
+                    const float gd = d[i][e] * gg[e];
+                    v[i][e] = xh;
+                    d[i][e] = gd;
+                    s1 += gd;
+                    s2 += gd * xh;
+                }
+            }
+        }
+        s1 = dvs::wave_sum(s1) / (float)C;
+        s2 = dvs::wave_sum(s2) / (float)C;
+        f32x4* dr = reinterpret_cast<f32x4*>(dx + (size_t)row * C);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (d[i][e] - s1 - v[i][e] * s2);
+                dr[c] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(dgamma + 4 * c + e, ag[i][e]);
+                atomicAdd(dbeta + 4 * c + e, ab[i][e]);
+            }
+        }
+    }
+}
+
+// ---- elementwise activations as their own passes (training keeps the pre-activation): 1 ReLU, 4 GELU (erf form) -----------
+__global__ __launch_bounds__(NT) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nvec, int act) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (size_t)gridDim.x * NT) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = act == 4 ? 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f)) : fmaxf(v[e], 0.f);
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// dx = dy * act'(x) from the INPUT x of the activation
+__global__ __launch_bounds__(NT) void act_bwd_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                        size_t nvec, int act) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (size_t)gridDim.x * NT) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (act == 4) {     // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+                const float cdf = 0.5f * (1.f + erff(v[e] * 0.70710678118654752f));
+                const float pdf = 0.3989422804014327f * __expf(-0.5f * v[e] * v[e]);
+                g[e] *= cdf + v[e] * pdf;
+            } else {
+                g[e] = v[e] > 0.f ? g[e] : 0.f;
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+}
+
+// ---- bilinear resize (align_corners=True) backward: scatter of dy [B,H,W,C] into dx [B,h,w,C] (zero-filled by the caller)
+__global__ __launch_bounds__(NT) void resize_bilinear_ac_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int h,
+                                                                    int w, int H, int W, int C) {
+    const int cv = C >> 2;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const size_t n = (size_t)B * H * W * cv;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % cv);
+        size_t t = i / cv;
+        const int X = (int)(t % W);
+        t /= W;
+        const int Y = (int)(t % H), b = (int)(t / H);
+        const float fy = sy * Y, fx = sx * X;
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        const f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+        float* xb = dx + ((size_t)b * h * w) * C + c * 4;
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(xb + ((size_t)y0 * w + x0) * C + e, g[e] * w00);
+            atomicAdd(xb + ((size_t)y0 * w + x1) * C + e, g[e] * w01);
+            atomicAdd(xb + ((size_t)y1 * w + x0) * C + e, g[e] * w10);
+            atomicAdd(xb + ((size_t)y1 * w + x1) * C + e, g[e] * w11);
+        }
+    }
+}
+
+// ---- inverse of deconv_shuffle: dg[b][i][j][(a k + c) Co + co] = dy[b][i k + a][j k + c][co] ------------------------------------
+__global__ __launch_bounds__(NT) void deconv_unshuffle_kernel(const float* __restrict__ dy, float* __restrict__ dg, int B, int h, int w,
+                                                              int k, int Co) {
+    const int cv = Co >> 2, H = h * k, W = w * k;
+    const size_t n = (size_t)B * H * W * cv;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % cv);
+        size_t t = i / cv;
+        const int X = (int)(t % W);
+        t /= W;
+        const int Y = (int)(t % H), b = (int)(t / H);
+        const int ii = Y / k, a = Y - ii * k, jj = X / k, cc = X - jj * k;
+        reinterpret_cast<f32x4*>(dg)[(((size_t)b * h + ii) * w + jj) * (size_t)(k * k * cv) + (size_t)(a * k + cc) * cv + c] =
+            reinterpret_cast<const f32x4*>(dy)[i];
+    }
+}
+
 inline unsigned sgrid(size_t n) {
     size_t b = (n + NT - 1) / NT;
     return (unsigned)(b > 4096 ? 4096 : (b == 0 ? 1 : b));
@@ -303,11 +688,11 @@ inline unsigned sgrid(size_t n) {
 
 extern "C" {
 
-int dvs_attention_fwd(const float* qkv, float* out, int B, int N, int heads, int head_dim, float scale, void* stream) {
+int dvs_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int head_dim, float scale, void* stream) {
     DVS_REQUIRE(qkv && out && B > 0 && N > 0 && heads > 0, "dvs_attention_fwd: bad argument");
     DVS_REQUIRE(head_dim == HD, "dvs_attention_fwd: head dimension 64 only (got %d)", head_dim);
     DVS_REQUIRE((double)B * N * 3 * heads * HD < 2147483648.0, "dvs_attention_fwd: qkv must have fewer than 2^31 elements");
-    AttnParams p{qkv, out, B, N, heads, scale};
+    AttnParams p{qkv, out, B, N, heads, scale, lse};
     hipStream_t st = static_cast<hipStream_t>(stream);
     {
         dvs::ProfScope prof(dvs::SLOT_ATTN, st);
@@ -359,6 +744,63 @@ int dvs_deconv_shuffle(const float* g, float* y, int B, int h, int w, int k, int
     const size_t n = (size_t)B * h * k * w * k * (Cout / 4);
     hipLaunchKernelGGL(deconv_shuffle_kernel, dim3(sgrid(n)), dim3(NT), 0, static_cast<hipStream_t>(stream), g, y, B, h, w, k, Cout);
     return dvs::check_launch("dvs_deconv_shuffle");
+}
+
+int dvs_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv, int B,
+                      int N, int heads, int head_dim, float scale, void* stream) {
+    DVS_REQUIRE(qkv && out && d_out && lse && delta && d_qkv && B > 0 && N > 0 && heads > 0, "dvs_attention_bwd: bad argument");
+    DVS_REQUIRE(head_dim == HD, "dvs_attention_bwd: head dimension 64 only (got %d)", head_dim);
+    DVS_REQUIRE((double)B * N * 3 * heads * HD < 2147483648.0, "dvs_attention_bwd: qkv must have fewer than 2^31 elements");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(attention_delta_kernel, dim3(sgrid((size_t)B * N * heads)), dim3(NT), 0, st, out, d_out, delta, B, N, heads);
+    AttnBwdParams p{qkv, d_out, lse, delta, d_qkv, B, N, heads, scale};
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((N + KT - 1) / KT, heads, B), dim3(NT), 0, st, p);
+    return dvs::check_launch("dvs_attention_bwd");
+}
+
+int dvs_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma_acc, float* dbeta_acc, int M, int C,
+                      float eps, void* stream) {
+    DVS_REQUIRE(x && gamma && dy && dx && dgamma_acc && dbeta_acc && M > 0 && C > 0 && (C & 3) == 0 && C <= 2048,
+                "dvs_layernorm_bwd: C %% 4 == 0, C <= 2048 (got %d)", C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks = (M + NT / 64 - 1) / (NT / 64);
+    blocks = blocks > 512 ? 512 : blocks;            // <= 2048 row-walking wavefronts: few atomics per channel
+    const dim3 grid(blocks);
+    if (C <= 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(NT), 0, st, x, gamma, dy, dx, dgamma_acc, dbeta_acc, M, C, eps);
+    else if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(NT), 0, st, x, gamma, dy, dx, dgamma_acc, dbeta_acc, M, C, eps);
+    else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, dim3(NT), 0, st, x, gamma, dy, dx, dgamma_acc, dbeta_acc, M, C, eps);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<8>, grid, dim3(NT), 0, st, x, gamma, dy, dx, dgamma_acc, dbeta_acc, M, C, eps);
+    return dvs::check_launch("dvs_layernorm_bwd");
+}
+
+int dvs_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
+    DVS_REQUIRE(x && y && n > 0 && (n & 3) == 0 && (act == 1 || act == 4), "dvs_act_fwd: n %% 4 == 0, act 1 (ReLU) or 4 (GELU)");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(sgrid(n / 4)), dim3(NT), 0, static_cast<hipStream_t>(stream), x, y, n / 4, act);
+    return dvs::check_launch("dvs_act_fwd");
+}
+
+int dvs_act_bwd_in(const float* x, const float* dy, float* dx, size_t n, int act, void* stream) {
+    DVS_REQUIRE(x && dy && dx && n > 0 && (n & 3) == 0 && (act == 1 || act == 4), "dvs_act_bwd_in: n %% 4 == 0, act 1 (ReLU) or 4 (GELU)");
+    hipLaunchKernelGGL(act_bwd_in_kernel, dim3(sgrid(n / 4)), dim3(NT), 0, static_cast<hipStream_t>(stream), x, dy, dx, n / 4, act);
+    return dvs::check_launch("dvs_act_bwd_in");
+}
+
+int dvs_resize_bilinear_ac_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream) {
+    DVS_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_resize_bilinear_ac_bwd: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * h * w * C * sizeof(float), st);
+    if (e != hipSuccess) return dvs::fail(DVS_ERR_LAUNCH, "dvs_resize_bilinear_ac_bwd: memset: %s", hipGetErrorString(e));
+    const size_t n = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(resize_bilinear_ac_bwd_kernel, dim3(sgrid(n)), dim3(NT), 0, st, dy, dx, B, h, w, H, W, C);
+    return dvs::check_launch("dvs_resize_bilinear_ac_bwd");
+}
+
+int dvs_deconv_unshuffle(const float* dy, float* dg, int B, int h, int w, int k, int Cout, void* stream) {
+    DVS_REQUIRE(dy && dg && B > 0 && h > 0 && w > 0 && k > 0 && Cout > 0 && (Cout & 3) == 0, "dvs_deconv_unshuffle: bad argument");
+    const size_t n = (size_t)B * h * k * w * k * (Cout / 4);
+    hipLaunchKernelGGL(deconv_unshuffle_kernel, dim3(sgrid(n)), dim3(NT), 0, static_cast<hipStream_t>(stream), dy, dg, B, h, w, k, Cout);
+    return dvs::check_launch("dvs_deconv_unshuffle");
 }
 
 }  // extern "C"

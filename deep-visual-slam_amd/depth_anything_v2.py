@@ -11,7 +11,12 @@ containers only; the arithmetic is HIP:
   * attention, LayerNorm, patchify, cls / pos-embed assembly, align_corners bilinear resizes and the stride == kernel
     ConvTranspose2d scatter are the kernels of csrc/vit.hip.
 
-Forward / inference only this round (eval + no_grad); ViT-G's SwiGLU FFN is not built (`encoder="vitg"` raises).
+Two paths behind the same `forward`: under `torch.no_grad()` the fused inference path (LayerScale folded into the proj / fc2
+weights, residuals and GELU in the GEMM epilogues, no saved tensors); with autograd enabled the TRAINABLE path -- the same
+kernels as autograd Functions (dvs_attention_fwd / _bwd with the saved log-sum-exp, dvs_layernorm_bwd, GELU / ReLU as their
+own passes so the pre-activation is kept, the implicit-GEMM engine's data / weight-gradient kernels for every Linear and
+convolution, dvs_resize_bilinear_ac_bwd, dvs_deconv_unshuffle), so the encoder swap can be fine-tuned by the VO trainer.
+ViT-G's SwiGLU FFN is not built (`encoder="vitg"` raises).
 """
 import math
 
@@ -48,7 +53,7 @@ def layernorm(x2d, weight, bias, eps):
 
 def attention(qkv2d, B, N, heads, head_dim):
     out = torch.empty(B * N, heads * head_dim, device=qkv2d.device, dtype=torch.float32)
-    check(_lib.lib().dvs_attention_fwd(ptr(qkv2d), ptr(out), B, N, heads, head_dim, head_dim ** -0.5, _lib.stream()), "dvs_attention_fwd")
+    check(_lib.lib().dvs_attention_fwd(ptr(qkv2d), ptr(out), None, B, N, heads, head_dim, head_dim ** -0.5, _lib.stream()), "dvs_attention_fwd")
     return out
 
 
@@ -70,11 +75,131 @@ def conv_transpose_s(x, w_gemm, bias_rep, k, cout):
     return y
 
 
-def _require_inference(x, who):
+# ---------------------------------------------------------------------------------------------- autograd Functions (training)
+class _AttentionF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv2d, B, N, heads, head_dim):
+        qkv2d = qkv2d.contiguous()
+        out = torch.empty(B * N, heads * head_dim, device=qkv2d.device, dtype=torch.float32)
+        lse = torch.empty(B, heads, N, device=qkv2d.device, dtype=torch.float32)
+        check(_lib.lib().dvs_attention_fwd(ptr(qkv2d), ptr(out), ptr(lse), B, N, heads, head_dim, head_dim ** -0.5, _lib.stream()),
+              "dvs_attention_fwd")
+        ctx.save_for_backward(qkv2d, out, lse)
+        ctx.dims = (B, N, heads, head_dim)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv2d, out, lse = ctx.saved_tensors
+        B, N, heads, hd = ctx.dims
+        d_out = d_out.contiguous()
+        d_qkv = torch.empty_like(qkv2d)
+        delta = torch.empty_like(lse)
+        check(_lib.lib().dvs_attention_bwd(ptr(qkv2d), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(d_qkv), B, N, heads, hd,
+                                           hd ** -0.5, _lib.stream()), "dvs_attention_bwd")
+        return d_qkv, None, None, None, None
+
+
+class _LayerNormF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, eps):
+        x2d = x2d.contiguous()
+        y = layernorm(x2d, weight.detach(), bias.detach(), eps)
+        ctx.save_for_backward(x2d, weight)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x2d)
+        dg, db = torch.zeros_like(weight), torch.zeros_like(weight)
+        check(_lib.lib().dvs_layernorm_bwd(ptr(x2d), ptr(weight.detach().contiguous()), ptr(dy), ptr(dx), ptr(dg), ptr(db), x2d.shape[0],
+                                           x2d.shape[1], ctx.eps, _lib.stream()), "dvs_layernorm_bwd")
+        return dx, dg, db, None
+
+
+_ACT_CODE = {"relu": 1, "gelu": 4}
+
+
+class _ActF(torch.autograd.Function):
+    """ReLU / GELU as its own pass over a dense tensor (any layout: elementwise); the backward reads the saved INPUT."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        if x.numel() % 4:
+            raise _lib.DvsError("activation: element count must be a multiple of 4")
+        dense = x if (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x.contiguous()
+        y = torch.empty_like(dense)
+        check(_lib.lib().dvs_act_fwd(dense.data_ptr(), y.data_ptr(), dense.numel(), _ACT_CODE[act], _lib.stream()), "dvs_act_fwd")
+        ctx.save_for_backward(dense)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        if dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=CL) if x.dim() == 4 and x.is_contiguous(memory_format=CL) and not x.is_contiguous() else dy.contiguous()
+        dx = torch.empty_like(x)
+        check(_lib.lib().dvs_act_bwd_in(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _ACT_CODE[ctx.act], _lib.stream()), "dvs_act_bwd_in")
+        return dx, None
+
+
+class _ResizeF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        ctx.in_hw = tuple(x.shape[2:])
+        return resize_bilinear_ac(x, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = dy.shape
+        h, w = ctx.in_hw
+        dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
+        dx = torch.empty((B, C, h, w), device=dy.device, dtype=torch.float32, memory_format=CL)
+        check(_lib.lib().dvs_resize_bilinear_ac_bwd(dy.data_ptr(), dx.data_ptr(), B, h, w, H, W, C, _lib.stream()), "dvs_resize_bilinear_ac_bwd")
+        return dx, None, None
+
+
+class _ShuffleF(torch.autograd.Function):
+    """[B, k*k*Co, h, w] (NHWC memory) -> [B, Co, h*k, w*k]: the scatter half of a stride == kernel ConvTranspose2d."""
+
+    @staticmethod
+    def forward(ctx, g, k, cout):
+        B, _, h, w = g.shape
+        g = g if g.is_contiguous(memory_format=CL) else g.contiguous(memory_format=CL)
+        y = torch.empty((B, cout, h * k, w * k), device=g.device, dtype=torch.float32, memory_format=CL)
+        check(_lib.lib().dvs_deconv_shuffle(g.data_ptr(), y.data_ptr(), B, h, w, k, cout, _lib.stream()), "dvs_deconv_shuffle")
+        ctx.dims = (B, h, w, k, cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, k, cout = ctx.dims
+        dy = dy if dy.is_contiguous(memory_format=CL) else dy.contiguous(memory_format=CL)
+        dg = torch.empty((B, k * k * cout, h, w), device=dy.device, dtype=torch.float32, memory_format=CL)
+        check(_lib.lib().dvs_deconv_unshuffle(dy.data_ptr(), dg.data_ptr(), B, h, w, k, cout, _lib.stream()), "dvs_deconv_unshuffle")
+        return dg, None, None
+
+
+def linear_train(x2d, weight, bias):
+    """x2d @ weight^T + bias with autograd, on the implicit-GEMM engine's forward / data-gradient / weight-gradient kernels
+    (a Linear is a 1x1 convolution of the [1, K, 1, M] token map)."""
+    N, K = weight.shape
+    y = _conv.conv2d(_as_map(x2d.contiguous()), weight.reshape(N, K, 1, 1), bias, 1, 0, 0, None)
+    return y.permute(0, 2, 3, 1).reshape(x2d.shape[0], N)
+
+
+def _require_gpu(x, who):
     if not x.is_cuda:
         raise _lib.DvsError("%s: GPU tensors only (got %s); this package has no CPU path" % (who, x.device))
-    if torch.is_grad_enabled() and x.requires_grad:
-        raise _lib.DvsError("%s: forward / inference only this round -- call under torch.no_grad()" % who)
+
+
+def _training_path(module):
+    """The differentiable path is taken when autograd is on and some parameter wants a gradient."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
 # ---------------------------------------------------------------------------------------------- DINOv2 (dinov2.py)
@@ -190,7 +315,8 @@ class DinoVisionTransformer(nn.Module):
         if npatch == N and w == h:
             return self.pos_embed[0]
         key = (w, h, self.pos_embed._version)
-        if getattr(self, "_pos_key", None) == key:
+        cacheable = not _training_path(self)
+        if cacheable and getattr(self, "_pos_key", None) == key:
             return self._pos_cache
         pos = self.pos_embed.float()
         dim = pos.shape[-1]
@@ -201,7 +327,8 @@ class DinoVisionTransformer(nn.Module):
                                           antialias=self.interpolate_antialias)
         assert int(w0) == patch.shape[-2] and int(h0) == patch.shape[-1]
         out = torch.cat((pos[:, 0], patch.permute(0, 2, 3, 1).reshape(-1, dim)), 0).contiguous()
-        self._pos_key, self._pos_cache = key, out
+        if cacheable:
+            self._pos_key, self._pos_cache = key, out.detach()
         return out
 
     def prepare_tokens(self, x):
@@ -233,19 +360,64 @@ class DinoVisionTransformer(nn.Module):
         h = gemm(h, w["fc1_w"], w["fc1_b"], act="gelu")
         return gemm(h, w["fc2_w"], w["fc2_b"], residual=x)
 
+    # ---- trainable path (autograd on): the same kernels as autograd Functions ------------------------------------------
+    def _prepare_tokens_train(self, x):
+        B, _, H, W = x.shape
+        P, C = self.patch_size, self.embed_dim
+        if H % P or W % P:
+            raise _lib.DvsError("DINOv2: image size %dx%d is not a multiple of the patch size %d" % (H, W, P))
+        K = 3 * P * P
+        Kp = (K + 31) // 32 * 32
+        Np = (H // P) * (W // P)
+        x = x.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        rows = torch.empty(B * Np, Kp, device=x.device, dtype=torch.float32)
+        check(_lib.lib().dvs_vit_patchify(ptr(x), ptr(rows), B, H, W, P, Kp, _lib.stream()), "dvs_vit_patchify")
+        w = nn.functional.pad(self.patch_embed.proj.weight.reshape(C, K), (0, Kp - K))      # tiny; autograd carries dW back
+        tok = linear_train(rows, w, self.patch_embed.proj.bias).view(B, Np, C)
+        pos = self.interpolate_pos_encoding(Np, H, W)
+        if pos.dim() == 2:
+            pos = pos.unsqueeze(0)
+        # cat + add: two small elementwise launches whose backward (slice, batch sum) autograd already has
+        xt = torch.cat((self.cls_token.expand(B, -1, -1), tok), 1) + pos
+        return xt.reshape(B * (Np + 1), C), B, Np + 1
+
+    def _block_train(self, x, blk, B, N):
+        C, heads = self.embed_dim, self.num_heads
+        h = _LayerNormF.apply(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+        qkv = linear_train(h, blk.attn.qkv.weight, blk.attn.qkv.bias)
+        a = _AttentionF.apply(qkv, B, N, heads, C // heads)
+        g1, g2 = blk.ls1.gamma, blk.ls2.gamma
+        # LayerScale rides in the weights here too (gamma * W, gamma * b are [C,C] / [C] products; autograd splits the
+        # gradient between gamma and W), so no [M,C] pass is spent on it
+        x = x + linear_train(a, blk.attn.proj.weight * g1[:, None], blk.attn.proj.bias * g1)
+        h = _LayerNormF.apply(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h = _ActF.apply(linear_train(h, blk.mlp.fc1.weight, blk.mlp.fc1.bias), "gelu")
+        return x + linear_train(h, blk.mlp.fc2.weight * g2[:, None], blk.mlp.fc2.bias * g2)
+
     def get_intermediate_layers(self, x, n=1, reshape=False, return_class_token=False, norm=True):
         """dinov2.py:297-321."""
-        _require_inference(x, "DINOv2")
-        prep = self._prepare()
-        tok, B, N = self.prepare_tokens(x)
+        _require_gpu(x, "DINOv2")
+        train = _training_path(self)
         take = list(range(len(self.blocks) - n, len(self.blocks))) if isinstance(n, int) else list(n)
         outs = []
-        for i, blk in enumerate(self.blocks):
-            tok = self._block(tok, blk, prep["blocks"][i], B, N)
-            if i in take:
-                outs.append(tok)
+        if train:
+            tok, B, N = self._prepare_tokens_train(x)
+            for i, blk in enumerate(self.blocks):
+                tok = self._block_train(tok, blk, B, N)
+                if i in take:
+                    outs.append(tok)
+        else:
+            prep = self._prepare()
+            tok, B, N = self.prepare_tokens(x)
+            for i, blk in enumerate(self.blocks):
+                tok = self._block(tok, blk, prep["blocks"][i], B, N)
+                if i in take:
+                    outs.append(tok)
         assert len(outs) == len(take)
-        if norm:
+        if norm and train:
+            outs = [_LayerNormF.apply(o, self.norm.weight, self.norm.bias, self.norm.eps) for o in outs]
+        elif norm:
             outs = [layernorm(o, self.norm.weight, self.norm.bias, self.norm.eps) for o in outs]
         outs = [o.view(B, N, self.embed_dim) for o in outs]
         cls = [o[:, 0] for o in outs]
@@ -277,6 +449,9 @@ class ResidualConvUnit(nn.Module):
     def forward(self, x, ones, zeros):
         """blocks.py:63-83: conv2(relu(conv1(relu(x)))) + x -- the leading ReLU is applied in conv1's gather (the skip needs
         the un-activated x), the second one in conv1's epilogue, the skip add in conv2's."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.conv1.weight.requires_grad):
+            out = _conv.conv2d(_ActF.apply(x, "relu"), self.conv1.weight, self.conv1.bias, 1, 1, 0, "relu")
+            return _conv.conv2d(out, self.conv2.weight, self.conv2.bias, 1, 1, 0, None) + x
         out = _conv.conv2d_forward(x, self.conv1.weight, self.conv1.bias, 1, 1, act="relu", in_scale=ones, in_shift=zeros, in_relu=True)
         return _conv.conv2d_forward(out, self.conv2.weight, self.conv2.bias, 1, 1, residual=x)
 
@@ -299,6 +474,9 @@ class FeatureFusionBlock(nn.Module):
             out = _add(out, res)
         out = self.resConfUnit2(out, ones, zeros)
         H, W = (size if size is not None else (out.shape[2] * 2, out.shape[3] * 2))
+        if torch.is_grad_enabled() and out.requires_grad:
+            out = _ResizeF.apply(out, int(H), int(W))
+            return _conv.conv2d(out, self.out_conv.weight, self.out_conv.bias, 1, 0, 0, None)
         out = resize_bilinear_ac(out, int(H), int(W))
         return _conv.conv2d_forward(out, self.out_conv.weight, self.out_conv.bias, 1, 0)
 
@@ -355,7 +533,40 @@ class DPTHead(nn.Module):
         self._prep, self._prep_sig = prep, sig
         return prep
 
+    def _forward_train(self, out_features, patch_h, patch_w):
+        """dpt.py:116-149 with autograd: every convolution through conv.conv2d (forward, data- and weight-gradient kernels)."""
+        out = []
+        for i, x in enumerate(out_features):
+            x = x[0]
+            B, Np, C = x.shape
+            x = x.reshape(B, patch_h, patch_w, C).permute(0, 3, 1, 2)
+            x = x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+            p = self.projects[i]
+            x = _conv.conv2d(x, p.weight, p.bias, 1, 0, 0, None)
+            if i < 2:
+                m = self.resize_layers[i]
+                k, co = m.kernel_size[0], m.weight.shape[1]
+                wg = m.weight.permute(2, 3, 1, 0).reshape(k * k * co, m.weight.shape[0], 1, 1)
+                x = _ShuffleF.apply(_conv.conv2d(x, wg, m.bias.repeat(k * k), 1, 0, 0, None), k, co)
+            elif i == 3:
+                r = self.resize_layers[3]
+                x = _conv.conv2d(x, r.weight, r.bias, 2, 1, 0, None)
+            out.append(x)
+        s = self.scratch
+        l1, l2, l3, l4 = (_conv.conv2d(o, m.weight, None, 1, 1, 0, None) for o, m in zip(out, (s.layer1_rn, s.layer2_rn, s.layer3_rn, s.layer4_rn)))
+        path_4 = s.refinenet4(None, None, l4, size=l3.shape[2:])
+        path_3 = s.refinenet3(None, None, path_4, l3, size=l2.shape[2:])
+        path_2 = s.refinenet2(None, None, path_3, l2, size=l1.shape[2:])
+        path_1 = s.refinenet1(None, None, path_2, l1)
+        o = _conv.conv2d(path_1, s.output_conv1.weight, s.output_conv1.bias, 1, 1, 0, None)
+        o = _ResizeF.apply(o, int(patch_h * 14), int(patch_w * 14))
+        c0, c2 = s.output_conv2[0], s.output_conv2[2]
+        o = _conv.conv2d(o, c0.weight, c0.bias, 1, 1, 0, "relu")
+        return _conv.head_conv2d(o, c2.weight, c2.bias, 0, 0, "sigmoid")
+
     def forward(self, out_features, patch_h, patch_w):
+        if torch.is_grad_enabled() and (out_features[0][0].requires_grad or _training_path(self)):
+            return self._forward_train(out_features, patch_h, patch_w)
         prep = self._prepare()
         ones, zeros = prep["ones"], prep["zeros"]
         out = []
@@ -398,7 +609,7 @@ class DepthAnythingV2(nn.Module):
         self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn, out_channels=out_channels, use_clstoken=use_clstoken)
 
     def forward(self, x):
-        _require_inference(x, "DepthAnythingV2")
+        _require_gpu(x, "DepthAnythingV2")
         patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
         feats = self.pretrained.get_intermediate_layers(x, self.intermediate_layer_idx[self.encoder], return_class_token=True)
         depth = self.depth_head(feats, patch_h, patch_w) * self.max_depth

@@ -6,9 +6,12 @@ launches.  The pool hands out views of one arena that is re-zeroed with a single
 begins (`reset()`, called by MonodepthTrainer.process_batch).  Callers that never reset simply exhaust
 the arena and fall back to torch.zeros, so the pool is an optimisation, never a requirement.
 """
+import os
+
 import torch
 
 _CAP = 40 * 1024 * 1024          # floats: all weight gradients (26.8 M) + statistics with room to spare
+_CHECK = os.environ.get("DVS_POOL_CHECK") == "1"      # debugging: verify at every reset that nothing beyond the handed-out prefix was written
 
 
 class _Pool:
@@ -21,7 +24,13 @@ class _Pool:
         if self.buf is None or self.buf.device != device:
             self.buf = torch.zeros(_CAP, device=device, dtype=torch.float32)
             self.off = 0
-        elif self.off:
+        elif self.off or _CHECK:
+            if _CHECK:
+                torch.cuda.synchronize()
+                dirty = int((self.buf[self.off:] != 0).sum())
+                if dirty:
+                    idx = int((self.buf[self.off:] != 0).nonzero()[0]) + self.off
+                    raise RuntimeError("zeropool: %d non-zero floats beyond the handed-out prefix (%d), first at %d" % (dirty, self.off, idx))
             self.buf[:self.off].zero_()
             self.off = 0
         self.active = True

@@ -390,7 +390,7 @@ int dvs_color_jitter(float* images, const void* records, float* workspace, int N
  * a14 / SURVEY.md 8(f) rank 1: Depth-Anything-V2 ViT-S (BASELINE.json configs[4]) -- forward kernels beside the
  *     implicit-GEMM engine (the token GEMMs are dvs_conv2d_fwd calls on [1,1,M,K] tensors).
  *   dvs_attention_fwd: out [B,N,heads*64] = softmax(q k^T * scale) v per head from qkv [B,N,3,heads,64] (the output of the
- *       qkv Linear), model/depth_anything_v2/dinov2_layers/attention.py:49-62; flash style on the fp32 matrix cores.
+ *       qkv Linear; lse may be NULL), model/depth_anything_v2/dinov2_layers/attention.py:49-62; flash style on the fp32 matrix cores.
  *   dvs_layernorm_fwd: nn.LayerNorm(C, eps) over the last dimension of x [M,C] (block.py:53,67; dinov2.py:166).
  *   dvs_vit_patchify: image [B,3,H,W] -> rows [B*(H/p)*(W/p)][k_padded], row = one patch in (ci, ky, kx) order, zero padded
  *       to k_padded (>= 3 p p, % 4 == 0): the A operand of PatchEmbed.proj (patch_embed.py:69-82).
@@ -400,8 +400,22 @@ int dvs_color_jitter(float* images, const void* records, float* workspace, int N
  *   dvs_deconv_shuffle: y [B,h*k,w*k,Cout] from g [B,h,w,k*k*Cout] = the 1x1 product of the input with the ConvTranspose2d
  *       weight arranged [(a*k+c)*Cout+co][ci]: nn.ConvTranspose2d(kernel_size=k, stride=k) of dpt.py:60-73.
  * ------------------------------------------------------------------------------------------- */
-int dvs_attention_fwd(const float* qkv, float* out, int B, int N, int heads, int head_dim, float scale, void* stream);
+int dvs_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int heads, int head_dim, float scale, void* stream);
 int dvs_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int M, int C, float eps, void* stream);
+/* Backward halves (training of the encoder swap).  lse [B,heads,N]: log-sum-exp of every score row, written by
+ * dvs_attention_fwd when non-NULL.  dvs_attention_bwd: d_qkv [B,N,3,heads,64] from d_out [B,N,heads*64] (delta [B,heads,N] is
+ * scratch); two recomputing kernels in the forward's register layout, no atomics.  dvs_layernorm_bwd: dx, and
+ * dgamma_acc / dbeta_acc += (caller zero-fills or accumulates).  dvs_act_fwd / dvs_act_bwd_in: ReLU (1) / GELU (4) as
+ * their own passes, the derivative taken from the activation's INPUT.  dvs_resize_bilinear_ac_bwd: dx [B,h,w,C] (zero-filled
+ * inside) from dy [B,H,W,C].  dvs_deconv_unshuffle: the inverse permutation of dvs_deconv_shuffle. */
+int dvs_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, float* delta, float* d_qkv, int B,
+                      int N, int heads, int head_dim, float scale, void* stream);
+int dvs_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma_acc, float* dbeta_acc, int M, int C,
+                      float eps, void* stream);
+int dvs_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
+int dvs_act_bwd_in(const float* x, const float* dy, float* dx, size_t n, int act, void* stream);
+int dvs_resize_bilinear_ac_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream);
+int dvs_deconv_unshuffle(const float* dy, float* dg, int B, int h, int w, int k, int Cout, void* stream);
 int dvs_vit_patchify(const float* image, float* rows, int B, int H, int W, int patch, int k_padded, void* stream);
 int dvs_vit_assemble(const float* patch_tokens, const float* cls_token, const float* pos_embed, float* x, int B, int num_patches,
                      int C, void* stream);

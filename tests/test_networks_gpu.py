@@ -132,7 +132,7 @@ def test_gradient_sinks_match_autograd_accumulation(gpu_device):
             scale = float(r.norm()) + 1e-30
             jitter, err = float((r - q).norm()) / scale, float((r - t).norm()) / scale
             worst = max(worst, (err, jitter, n))
-            assert jitter <= 2e-5 and err <= 2e-5, (n, err, jitter)           # measured 1.8e-6 (profiles/r02_d_deterministic_tests.log)
+            assert jitter <= 2e-5 and err <= 2e-5, (n, err, jitter, float(r.norm()), float(q.norm()), float(t.norm()), float((q - t).norm()))   # measured 1.8e-6
     print("worst sink-vs-autograd rel-L2 %.2e (run-to-run there %.2e) at %s" % worst)
     assert float((s2 - 2 * s1).norm()) <= 2e-5 * float(s1.norm())
     assert set(fired) == set(flat.names), sorted(set(flat.names) - set(fired))
