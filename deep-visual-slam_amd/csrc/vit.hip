@@ -662,6 +662,39 @@ __global__ __launch_bounds__(NT) void resize_bilinear_ac_bwd_kernel(const float*
     }
 }
 
+
+// scalar-channel forms of the two resize kernels (C not a multiple of 4: the 1-channel disparity maps and 3-channel images
+// of the encoder-swap adapter)
+__global__ __launch_bounds__(NT) void resize_bilinear_ac_scalar_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                       float* __restrict__ dx, int B, int h, int w, int H, int W,
+                                                                       int C) {
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        size_t t = i / C;
+        const int X = (int)(t % W);
+        t /= W;
+        const int Y = (int)(t % H), b = (int)(t / H);
+        const float fy = sy * Y, fx = sx * X;
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        const size_t base = (size_t)b * h * w * C + c;
+        const size_t o00 = base + ((size_t)y0 * w + x0) * C, o01 = base + ((size_t)y0 * w + x1) * C;
+        const size_t o10 = base + ((size_t)y1 * w + x0) * C, o11 = base + ((size_t)y1 * w + x1) * C;
+        if (dx == nullptr) {
+            y[i] = (1.f - ly) * ((1.f - lx) * x[o00] + lx * x[o01]) + ly * ((1.f - lx) * x[o10] + lx * x[o11]);
+        } else {                      // backward: x = dy (read at i), scatter into dx
+            const float g = x[i];
+            atomicAdd(dx + o00, g * (1.f - ly) * (1.f - lx));
+            atomicAdd(dx + o01, g * (1.f - ly) * lx);
+            atomicAdd(dx + o10, g * ly * (1.f - lx));
+            atomicAdd(dx + o11, g * ly * lx);
+        }
+    }
+}
+
 // ---- inverse of deconv_shuffle: dg[b][i][j][(a k + c) Co + co] = dy[b][i k + a][j k + c][co] ------------------------------------
 __global__ __launch_bounds__(NT) void deconv_unshuffle_kernel(const float* __restrict__ dy, float* __restrict__ dg, int B, int h, int w,
                                                               int k, int Co) {
@@ -733,7 +766,12 @@ int dvs_vit_assemble(const float* patch_tokens, const float* cls_token, const fl
 }
 
 int dvs_resize_bilinear_ac(const float* x, float* y, int B, int h, int w, int H, int W, int C, void* stream) {
-    DVS_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_resize_bilinear_ac: bad argument");
+    DVS_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "dvs_resize_bilinear_ac: bad argument");
+    if (C & 3) {
+        hipLaunchKernelGGL(resize_bilinear_ac_scalar_kernel, dim3(sgrid((size_t)B * H * W * C)), dim3(NT), 0, static_cast<hipStream_t>(stream), x,
+                           y, static_cast<float*>(nullptr), B, h, w, H, W, C);
+        return dvs::check_launch("dvs_resize_bilinear_ac");
+    }
     const size_t n = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(resize_bilinear_ac_kernel, dim3(sgrid(n)), dim3(NT), 0, static_cast<hipStream_t>(stream), x, y, B, h, w, H, W, C);
     return dvs::check_launch("dvs_resize_bilinear_ac");
@@ -787,10 +825,15 @@ int dvs_act_bwd_in(const float* x, const float* dy, float* dx, size_t n, int act
 }
 
 int dvs_resize_bilinear_ac_bwd(const float* dy, float* dx, int B, int h, int w, int H, int W, int C, void* stream) {
-    DVS_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_resize_bilinear_ac_bwd: bad argument");
+    DVS_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0, "dvs_resize_bilinear_ac_bwd: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dx, 0, (size_t)B * h * w * C * sizeof(float), st);
     if (e != hipSuccess) return dvs::fail(DVS_ERR_LAUNCH, "dvs_resize_bilinear_ac_bwd: memset: %s", hipGetErrorString(e));
+    if (C & 3) {
+        hipLaunchKernelGGL(resize_bilinear_ac_scalar_kernel, dim3(sgrid((size_t)B * H * W * C)), dim3(NT), 0, st, dy, static_cast<float*>(nullptr),
+                           dx, B, h, w, H, W, C);
+        return dvs::check_launch("dvs_resize_bilinear_ac_bwd");
+    }
     const size_t n = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(resize_bilinear_ac_bwd_kernel, dim3(sgrid(n)), dim3(NT), 0, st, dy, dx, B, h, w, H, W, C);
     return dvs::check_launch("dvs_resize_bilinear_ac_bwd");

@@ -624,3 +624,37 @@ class DepthAnythingV2(nn.Module):
             if s:
                 out[("disp", s)] = nn.functional.interpolate(d, scale_factor=1.0 / (2 ** s), mode="bilinear", align_corners=True)
         return out
+
+
+class DepthAnythingDispNet(nn.Module):
+    """The "encoder swap" of BASELINE configs[4]: a DepthNet-shaped wrapper (`forward(x [B,3,H,W] in [0,1]) ->
+    {("disp", s): [B,1,H/2^s,W/2^s]}`, model/depthnet.py:64-90) around DepthAnythingV2, so that MonodepthTrainer / vo/train.py
+    can train it in place of the ResNet DepthNet.  Resize policy: the frame is resampled (bilinear, align_corners=True) to
+    the largest multiples of 14 that fit (480x640 -> 476x630 = 34x45 patches), normalised with the ImageNet statistics the
+    reference's `image2tensor` applies (dpt.py:214-216), and the head's sigmoid map is resampled back to H/2^s x W/2^s."""
+
+    def __init__(self, encoder="vits", features=64, out_channels=(48, 96, 192, 384), scales=range(4)):
+        super().__init__()
+        self.net = DepthAnythingV2(encoder=encoder, features=features, out_channels=list(out_channels))
+        self.scales = list(scales)
+        self.register_buffer("mean", torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), persistent=False)
+        self.register_buffer("std", torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1), persistent=False)
+
+    def forward(self, x):
+        _require_gpu(x, "DepthAnythingDispNet")
+        B, _, H, W = x.shape
+        h14, w14 = H // 14 * 14, W // 14 * 14
+        xin = x
+        if (h14, w14) != (H, W):
+            xin = resize_bilinear_ac(x.contiguous(memory_format=CL), h14, w14).contiguous()
+        xin = (xin - self.mean) / self.std
+        d = (self.net(xin) / self.net.max_depth).unsqueeze(1)               # the head's sigmoid output, [B,1,h14,w14]
+        train = torch.is_grad_enabled() and d.requires_grad
+        out = {}
+        for s in self.scales:
+            hs, ws = H // (2 ** s), W // (2 ** s)
+            if (hs, ws) == tuple(d.shape[2:]):
+                out[("disp", s)] = d
+            else:
+                out[("disp", s)] = _ResizeF.apply(d, hs, ws) if train else resize_bilinear_ac(d, hs, ws)
+        return out

@@ -241,3 +241,48 @@ def test_depth_anything_gradients_vs_oracle(gpu_device):
     print("DA-V2 gradients vs oracle: worst", rows[:3], "median %.2e over %d tensors" % (rows[len(rows) // 2][0], len(rows)))
     # ReLU branches in the DPT head only (8 ResidualConvUnits + output conv): smooth elsewhere (GELU, softmax, LayerNorm)
     assert rows[0][0] < 2e-3 and rows[len(rows) // 2][0] < 1e-4, rows[:5]
+
+
+def test_encoder_swap_trains_in_the_vo_trainer(gpu_device):
+    """DepthAnythingDispNet in place of DepthNet inside MonodepthTrainer (BASELINE configs[4]: "encoder swap"): the adapter's
+    disparity pyramid against the oracle composition, then one full VO training step (fused loss chain + backward through the
+    DPT head, the 12 transformer blocks and PoseNet) with finite gradients on every trained tensor and a loss that goes down
+    over a few Adam steps."""
+    from deep_visual_slam_amd import synth
+    from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingDispNet
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    from oracle import depth_anything as OD
+    B, H, W = 2, 96, 128
+    torch.manual_seed(0)
+    dn = DepthAnythingDispNet().to(gpu_device).train()
+    pn = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
+    sample = synth.parity_sample(B, H, W)
+    x = sample[("target_image", 0)]
+    # adapter vs oracle: resize to 84x126, ImageNet normalisation, DA-V2, sigmoid map resized to the pyramid
+    sd = {k: v.detach().cpu() for k, v in dn.net.state_dict().items()}
+    with torch.no_grad():
+        xin = F.interpolate(x, (84, 126), mode="bilinear", align_corners=True)
+        xin = (xin - torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)) / torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+        d_ref = (OD.depth_anything_v2(xin, sd) / 20.0).unsqueeze(1)
+        out = dn(x.to(gpu_device))
+    for s in range(4):
+        ref = F.interpolate(d_ref, (H >> s, W >> s), mode="bilinear", align_corners=True)
+        assert out[("disp", s)].shape == ref.shape and rel(out[("disp", s)], ref) < 2e-5, s
+    cfg = {"Train": dict(num_source=1, batch_size=B, img_h=H, img_w=W, smoothness_ratio=0.001, auto_mask=True,
+                         ssim_ratio=0.85, min_depth=0.1, max_depth=10.0, use_compile=False)}
+    tr = MonodepthTrainer(dn, pn, cfg, gpu_device)
+    opt = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), lr=1e-4)
+    seen = []
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        outputs, losses = tr.process_batch(dict(sample))
+        losses["loss"].backward()
+        if it == 0:
+            missing = [n for n, p in dn.named_parameters() if p.grad is None and "mask_token" not in n]
+            assert not missing, missing[:5]
+            assert all(torch.isfinite(p.grad).all() for p in dn.parameters() if p.grad is not None)
+            assert float(dict(dn.named_parameters())["net.pretrained.blocks.0.attn.qkv.weight"].grad.abs().max()) > 0
+        opt.step()
+        seen.append(float(losses["loss"]))
+    assert all(np.isfinite(seen)) and seen[-1] < seen[0], seen
