@@ -10,6 +10,7 @@ out of a kernel.  One call covers what the reference spells as several modules:
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -108,7 +109,7 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
     return y
 
 
-_prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape)
+_prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape, weakref to the weight)
 
 
 def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0):
@@ -157,7 +158,9 @@ class PackedWeights:
         check(_lib.lib().dvs_conv2d_pack_wt_batch(self.table.data_ptr(), len(self.weights), self.total_wgs, _lib.stream()),
               "dvs_conv2d_pack_wt_batch")
         for w, wt in zip(self.weights, self.packs):
-            _prepacked[w.data_ptr()] = (wt, w._version, tuple(w.shape))
+            # the weak reference pins the entry to THIS tensor object: the caching allocator hands the address of a freed
+            # arena to the next one, and a pack of the old network must never serve the new network's data gradient
+            _prepacked[w.data_ptr()] = (wt, w._version, tuple(w.shape), weakref.ref(w))
 
     def release(self):
         for w in self.weights:
@@ -167,7 +170,7 @@ class PackedWeights:
 def _packed_weight(w, weight):
     """[Cin][kh][kw][Cout] operand of the data gradient: the optimiser's pre-packed copy when it is current, else packed here."""
     ent = _prepacked.get(w.data_ptr())
-    if ent is not None and ent[1] == weight._version and ent[2] == tuple(weight.shape):
+    if ent is not None and ent[3]() is not None and ent[1] == weight._version and ent[2] == tuple(weight.shape):
         return ent[0]
     Cout, Cin, kh, kw = weight.shape
     wt = torch.empty(Cin * kh * kw * Cout, device=w.device, dtype=torch.float32)

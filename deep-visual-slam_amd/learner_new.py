@@ -166,6 +166,13 @@ class MonodepthTrainer:
         losses = self._fused_losses(sample, outputs)
         return outputs, losses
 
+    def __del__(self):
+        try:
+            if self._arena_packs is not None:
+                self._arena_packs.release()
+        except Exception:
+            pass
+
     def _arena_prepare(self):
         """Start of a training step on the trainer-owned arena: gradients that the caller set to None are re-attached to
         the (re-zeroed) gradient arena so the kernels can sink into them; the data-gradient weight packs are refreshed with
