@@ -290,7 +290,7 @@ def test_one_line_optimizer_swap_keeps_the_caller_sequence(gpu_device):
     (l_a, w_a, lr_a), (l_b, w_b, lr_b) = results
     assert lr_a == lr_b and lr_a < LR
     for k in l_a[0]:
-        assert abs(l_a[0][k] - l_b[0][k]) < 1e-6 * abs(l_a[0][k])              # same weights, same kernels
+        assert abs(l_a[0][k] - l_b[0][k]) < 1e-5 * abs(l_a[0][k])              # same weights, same kernels (BatchNorm statistics are summed with float atomics: 2e-6 run to run)
         assert abs(l_a[1][k] - l_b[1][k]) < 1e-3 * abs(l_a[1][k])              # after one sign-like Adam update
     n_bad = n_all = 0
     for k in w_a:
