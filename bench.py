@@ -327,6 +327,36 @@ def dav2_side(device, with_cpu, batches=(1, 8)):
             del gnet
         res["batches"]["batch_%d" % B] = entry
     res["value"] = res["batches"]["batch_%d" % batches[-1]]["value"]
+    # the trainable path (autograd on): forward + backward of a scalar loss, batch 4
+    Bt = 4
+    net.train()
+    xt = torch.randn(Bt, 3, 518, 518, device=device)
+
+    def train_pass():
+        net.zero_grad(set_to_none=True)
+        net(xt).mean().backward()
+
+    for _ in range(2):
+        train_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        train_pass()
+    torch.cuda.synchronize()
+    dtt = (time.perf_counter() - t0) / 5
+    dp.profile_enable(True)
+    for _ in range(2):
+        train_pass()
+    torch.cuda.synchronize()
+    prof = dp.profile_read()
+    dp.profile_enable(False)
+    tr = {"batch": Bt, "ms_per_forward_backward": dtt * 1e3, "value": Bt / dtt}
+    for k in ("attention_fwd_kernel", "attention_bwd_kernel", "conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel"):
+        if k in prof:
+            ms, cnt, fl = prof[k]
+            tr[k] = {"ms": ms / 2, "launches": cnt / 2, "tflops": fl / (ms * 1e-3) / 1e12}
+    res["train"] = tr
+    net.eval()
     if with_cpu:
         from oracle import depth_anything as OD
         cores = min(len(os.sched_getaffinity(0)), 16)

@@ -45,7 +45,7 @@ inline int check_launch(const char* what) {
 
 // ---- per-kernel timing with HIP events on the launch stream (include/dvslam.h: dvs_profile_*)
 enum ProfSlot { SLOT_CHAIN_FWD = 0, SLOT_CHAIN_BWD, SLOT_ADAM, SLOT_CONV_FWD, SLOT_CONV_DGRAD, SLOT_CONV_WGRAD,
-                SLOT_BN_FWD, SLOT_BN_BWD, SLOT_ATTN, SLOT_COUNT };
+                SLOT_BN_FWD, SLOT_BN_BWD, SLOT_ATTN, SLOT_ATTN_BWD, SLOT_COUNT };
 bool prof_enabled();
 void prof_begin(int slot, hipStream_t st, hipEvent_t* start);
 void prof_end(int slot, hipStream_t st, hipEvent_t start);

@@ -34,7 +34,7 @@ long g_n[SLOT_COUNT];
 double g_work[SLOT_COUNT];   // algorithmic flops (MFMA kernels) or bytes (HBM kernels) of the recorded launches
 const char* kSlotNames[SLOT_COUNT] = {"chain_fwd_kernel", "chain_bwd_kernel", "adam_kernel", "conv_fwd_kernel",
                                       "conv_dgrad_kernel", "conv_wgrad_kernel", "bn_fwd_kernel", "bn_bwd_kernel",
-                                      "attention_fwd_kernel"};
+                                      "attention_fwd_kernel", "attention_bwd_kernel"};
 
 void drain_locked(int slot) {
     for (Pair& p : g_pairs[slot]) {

@@ -792,8 +792,12 @@ int dvs_attention_bwd(const float* qkv, const float* out, const float* d_out, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(attention_delta_kernel, dim3(sgrid((size_t)B * N * heads)), dim3(NT), 0, st, out, d_out, delta, B, N, heads);
     AttnBwdParams p{qkv, d_out, lse, delta, d_qkv, B, N, heads, scale};
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((N + KT - 1) / KT, heads, B), dim3(NT), 0, st, p);
+    {
+        dvs::ProfScope prof(dvs::SLOT_ATTN_BWD, st);
+        prof.work(8.0 * B * heads * (double)N * N * HD);      // algorithmic: dV, dP, dQ, dK (the two kernels also recompute S and dP)
+        hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((N + KT - 1) / KT, heads, B), dim3(NT), 0, st, p);
+    }
     return dvs::check_launch("dvs_attention_bwd");
 }
 
