@@ -76,7 +76,7 @@ class _BNAct(torch.autograd.Function):
         need_du = ctx.relu or residual is not None
         du = torch.empty_like(y) if need_du else dz
         dy = torch.empty_like(y)
-        pooled = gamma.grad is not None
+        pooled = gamma.is_leaf and gamma.grad is not None
         sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
         ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
         g_par, b_par, rg_par, rb_par = ctx.affine

@@ -21,6 +21,12 @@ ACT = {None: 0, "none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "gelu": 4}
 CL = torch.channels_last
 
 
+def _has_grad(t):
+    """A leaf tensor with an existing .grad (autograd will then add the returned gradient in place and never adopt it, so it
+    may live in the step-scoped scratch pool); non-leaf weights (gamma * W, reshaped ConvTranspose weights) never qualify."""
+    return t is not None and t.is_leaf and t.grad is not None
+
+
 def _nhwc(t):
     """Contiguous-NHWC requirement (a [B,1,H,W] or [B,C,1,1] tensor is both NCHW and NHWC)."""
     if t.dtype != torch.float32:
@@ -291,7 +297,7 @@ class _Conv2d(torch.autograd.Function):
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
                     db_ptr, pre_db = bs.data_ptr(), True
                 else:
-                    pre_db = zeropool.zeros((Cout,), dy.device, pooled=ctx.bias_ref.grad is not None)
+                    pre_db = zeropool.zeros((Cout,), dy.device, pooled=_has_grad(ctx.bias_ref))
                     db_ptr = pre_db.data_ptr()
             check(_lib.lib().dvs_act_bwd(dy.data_ptr(), _nhwc(y).data_ptr(), dz.data_ptr(), dy.numel(), ACT[act], db_ptr, Cout,
                                          _lib.stream()), "dvs_act_bwd")
@@ -334,7 +340,7 @@ class _Conv2d(torch.autograd.Function):
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
                 dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                       in_scale=scale, in_shift=shift, nchw_planar=planar,
-                                      pooled=weight.grad is not None, dw_out=wsink, db_out=bsink_w)
+                                      pooled=_has_grad(weight), dw_out=wsink, db_out=bsink_w)
                 if pre_db is not None and pre_db is not True:
                     db = pre_db
             else:
@@ -364,7 +370,7 @@ class _HeadConv(torch.autograd.Function):
         check(_lib.lib().dvs_conv2d_head_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), ACT[act],
                                              _lib.stream()), "dvs_conv2d_head_fwd")
         ctx.cfg = (pad, reflect, act, bias is not None)
-        ctx.pooled = weight.grad is not None and (bias is None or bias.grad is not None)
+        ctx.pooled = _has_grad(weight) and (bias is None or _has_grad(bias))
         ctx.params = (weight, bias)              # only to find their gradient sinks in backward
         ctx.save_for_backward(x, w, y)
         return y
