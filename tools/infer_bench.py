@@ -1,5 +1,6 @@
 """Frames/s of the inference path at batch 1 (vo/predict.py's per-frame work: PoseNet on the frame pair, DepthNet on the
-target frame, pose matrix, depth): eager vs HIP-graph replay; DVS_CONV_BACKEND=miopen gives the library baseline.
+target frame, pose matrix, depth): eager vs HIP-graph replay (the library-convolution baseline of round 1 is gone with
+the fallback path: profiles/r01_d_infer_bench.txt keeps its numbers).
 usage: infer_bench.py [frames] [--cpu]   (--cpu: also time the CPU oracle's eval-mode networks on a few frames)"""
 import json, os, sys, time
 import torch
@@ -38,10 +39,10 @@ def timeit(depth, pose, n):
     return (time.perf_counter() - t0) / n
 
 
-res = {"backend": nn_ops.conv_backend(), "frames": n, "image": "640x480", "batch": 1}
+res = {"backend": "hip", "frames": n, "image": "640x480", "batch": 1}
 t = timeit(dn, pn, n)
 res["eager_ms"] = round(t * 1e3, 3); res["eager_fps"] = round(1 / t, 1)
-if nn_ops.conv_backend() == "hip":
+if True:
     gd, gp = inference.Graphed(dn, tgt), inference.Graphed(pn, pair)
     t = timeit(gd, gp, n)
     res["graph_ms"] = round(t * 1e3, 3); res["graph_fps"] = round(1 / t, 1)
