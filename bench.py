@@ -24,6 +24,13 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("DVS_BENCH_REHEARSE") != "1":
+    # One rank per GPU: the step uses four compute streams and the all-reduce a fifth.  HIP maps a process's streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so give the all-reduce a queue
+    # of its own (4 / 6 / 8 queues measured neutral for the single-GPU step, gpurun_out sweep).  Set
+    # before torch loads the HIP runtime, which reads its flags once.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
 import torch
 import torch.distributed as dist
 
@@ -409,12 +416,6 @@ def main():
     rehearse = os.environ.get("DVS_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
-    if world > 1 and not rehearse:
-        # One rank per GPU: the step uses four compute streams and the all-reduce a fifth.  HIP maps a process's streams onto
-        # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so give the all-reduce a
-        # queue of its own (5-8 queues measured neutral for the single-GPU step).  Must be set before
-        # the HIP runtime initialises, i.e. before the first torch.cuda call below.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
