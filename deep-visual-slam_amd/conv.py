@@ -157,6 +157,17 @@ class PackedWeights:
             wg += kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
         self.total_wgs = wg
         self.table = torch.tensor(rows, dtype=torch.int64, device=self.weights[0].device) if rows else None
+        # Winograd operands (both orientations) of the stride-1 3x3 weights that qualify by shape
+        self.wino = [w for w in self.weights if wino_eligible(w, 1, 1, False, None, None, False, None)]
+        self.wino_ops, rows, wg = [], [], 0
+        for w in self.wino:
+            co, ci = w.shape[:2]
+            u, uf = _wino_alloc(w), _wino_alloc(w)
+            self.wino_ops.append((u, uf))
+            rows.append([w.data_ptr(), u.data_ptr(), uf.data_ptr(), co | (ci << 32), wg])       # csrc/conv_wino.hip WinoEntry
+            wg += (co * ci + 255) // 256
+        self.wino_wgs = wg
+        self.wino_table = torch.tensor(rows, dtype=torch.int64, device=self.weights[0].device) if rows else None
 
     def repack(self):
         if self.table is None:
@@ -167,21 +178,82 @@ class PackedWeights:
             # the weak reference pins the entry to THIS tensor object: the caching allocator hands the address of a freed
             # arena to the next one, and a pack of the old network must never serve the new network's data gradient
             _prepacked[w.data_ptr()] = (wt, w._version, tuple(w.shape), weakref.ref(w))
+        if self.wino_table is not None:
+            check(_lib.lib().dvs_wino_weights_batch(self.wino_table.data_ptr(), len(self.wino), self.wino_wgs, _lib.stream()),
+                  "dvs_wino_weights_batch")
+            for w, (u, uf) in zip(self.wino, self.wino_ops):
+                _wino_packed[w.data_ptr()] = [u, uf, w._version, tuple(w.shape), weakref.ref(w)]
 
     def release(self):
         for w in self.weights:
             _prepacked.pop(w.data_ptr(), None)
+            _wino_packed.pop(w.data_ptr(), None)
 
 
 def _packed_weight(w, weight):
     """[Cin][kh][kw][Cout] operand of the data gradient: the optimiser's pre-packed copy when it is current, else packed here."""
     ent = _prepacked.get(w.data_ptr())
-    if ent is not None and ent[3]() is not None and ent[1] == weight._version and ent[2] == tuple(weight.shape):
+    if ent is not None and ent[3]() is weight and ent[1] == weight._version and ent[2] == tuple(weight.shape):
         return ent[0]
     Cout, Cin, kh, kw = weight.shape
     wt = torch.empty(Cin * kh * kw * Cout, device=w.device, dtype=torch.float32)
     check(_lib.lib().dvs_conv2d_pack_wt(w.data_ptr(), wt.data_ptr(), Cout, Cin, kh, kw, _lib.stream()), "dvs_conv2d_pack_wt")
     return wt
+
+
+# ---- Winograd F(2x2, 3x3) path of the stride-1 3x3 BasicBlock convolutions (csrc/conv_wino.hip) ------------------------
+_WINO = os.environ.get("DVS_WINOGRAD", "1") != "0"
+_wino_packed = {}   # weight.data_ptr() -> [u, u_flip, weight._version, shape, weakref]  (either operand may be None)
+
+
+def wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale):
+    """Forward AND data gradient of this convolution run on the Winograd kernel: 3x3, stride 1, zero pad 1, no fused input
+    transform or activation, both channel counts multiples of 16 (the kernels' K chunking) and wide enough to fill the
+    32-channel MFMA columns."""
+    co, ci, kh, kw = weight.shape
+    return (_WINO and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not reflect and act is None and x2 is None
+            and not planar and scale is None and ci % 16 == 0 and co % 16 == 0 and ci >= 64 and co >= 64)
+
+
+def _wino_alloc(weight):
+    co, ci = weight.shape[:2]
+    return torch.empty(co * ci * 16, device=weight.device, dtype=torch.float32)
+
+
+def _wino_weight(w, weight, flip):
+    """G g G^T operand of the Winograd kernel ([K][4][N][4]; flip: the data gradient's rotated / transposed filter): the
+    optimiser's pre-transformed copy when it is current, else transformed here and kept until the weight changes."""
+    # keyed by the WEIGHT's own address (w may be a temporary NHWC copy whose address the allocator hands out again) and
+    # pinned to the weight OBJECT: a live parameter whose storage moved (an arena, .to()) leaves its old address to others
+    ent = _wino_packed.get(weight.data_ptr())
+    if not (ent is not None and ent[4]() is weight and ent[2] == weight._version and ent[3] == tuple(weight.shape)):
+        if len(_wino_packed) > 1024:
+            for k in [k for k, e in _wino_packed.items() if e[4]() is None]:
+                del _wino_packed[k]
+        ent = [None, None, weight._version, tuple(weight.shape), weakref.ref(weight)]
+        _wino_packed[weight.data_ptr()] = ent
+    if ent[int(flip)] is None:
+        u = _wino_alloc(weight)
+        check(_lib.lib().dvs_wino_weights(w.data_ptr(), u.data_ptr(), weight.shape[0], weight.shape[1], int(flip), _lib.stream()),
+              "dvs_wino_weights")
+        ent[int(flip)] = u
+    return ent[int(flip)]
+
+
+def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False):
+    """y = conv3x3(x, weight) (stride 1, zero pad 1) on the Winograd kernel; flip: the data gradient of that convolution,
+    x = dY [B,Cout,H,W] -> dX [B,Cin,H,W].  `weight` must be the parameter object itself (the operand cache is pinned to it)."""
+    x, w = _nhwc(x), _nhwc(weight)
+    co, ci = weight.shape[:2]
+    k, n = (co, ci) if flip else (ci, co)
+    B, cx, H, W = x.shape
+    if cx != k:
+        raise _lib.DvsError("conv3x3_wino: input has %d channels, the operand expects %d" % (cx, k))
+    u = _wino_weight(w, weight, flip)
+    y = torch.empty((B, n, H, W), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0,
+                                          B, H, W, k, n, 0, int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
+    return y
 
 
 def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False):
@@ -258,12 +330,18 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
         groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
         stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
-        y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
-                           nchw_planar=planar, stats=stats, stat_groups=max(groups, 1))
+        ctx.wino = (bias is None and wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale) and x.shape[1] == weight.shape[1]
+                    and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)      # 32-bit buffer offsets
+        if ctx.wino:
+            y = conv3x3_wino(x, weight, stats, groups)
+        else:
+            y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
+                               nchw_planar=planar, stats=stats, stat_groups=max(groups, 1))
         ctx.opts = opts[:7]
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                      # only to find its gradient sink in backward
+        ctx.weight_ref = weight                  # the object the operand caches (_prepacked, _wino_packed) are pinned to
         ctx.up_only = x2 is UPSAMPLE_ONLY
         ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
         if want_stats:
@@ -273,7 +351,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
-        x, weight, x2, y = ctx.saved_tensors
+        x, weight, x2, y = ctx.saved_tensors     # (unpacking also runs autograd's in-place modification check)
+        weight = ctx.weight_ref                  # same data; the parameter object itself for the cache lookups
         stride, pad, reflect, act, planar, scale, shift = ctx.opts
         dx = dx2 = dw = db = None
         if dy is None:
@@ -310,7 +389,9 @@ class _Conv2d(torch.autograd.Function):
             B = ctx.x_shape[0]
             padded = (_PADDED and preact and reflect and stride == 1 and pad == 1 and weight.shape[2] == 3
                       and weight.shape[0] % 32 == 0 and ctx.x_shape[2] >= 2)
-            if x2 is None:
+            if ctx.wino:
+                dx = conv3x3_wino(dy, weight, flip=True)
+            elif x2 is None:
                 if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:
                     dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape)
                 else:

@@ -1,0 +1,457 @@
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions of the ResNet encoder (62 % of the path's flops) on the fp32 matrix
+// cores -- experiment of round 2 (DESIGN.md section 7 has the analysis; tools/wino_bench.py the measurement).
+//
+//   Y = A^T [ (G g G^T) o (B^T d B) ] A        per 2x2 output tile, 4x4 input tile d, 3x3 filter g
+//
+// 16 products per 4 outputs instead of 36: 2.25x fewer MFMAs.  The 16 transform components xi are 16 independent GEMMs
+// [tiles x Cin] x [Cin x Cout]; a wave keeps all 16 accumulator tiles (32 tiles x 32 output channels each = 256 registers,
+// one wave per SIMD) so that the output transform is in-lane: in the C/D map of v_mfma_f32_32x32x2_f32 a lane holds output
+// channel (lane & 31) of 16 tiles, the same register index in all 16 accumulators.
+//   A operand (xi): V_xi[tile][c] = (B^T d B)_xi, transformed once per workgroup and chunk of channels into LDS (see the kernel);
+//   B operand (xi): U_xi[c][cout] = (G g G^T)_xi, transformed once per optimiser step into [Cin][4][Cout][4] (wino_weights_kernel)
+//                   and read straight from L2 (four coalesced float4 per lane and k-step), prefetched one k-step ahead.
+// Data gradient of the same convolution = the same kernel on dY with the filter rotated by 180 degrees and transposed
+// (flip != 0 in the weight transform).
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int NT = 256;
+constexpr int CIN_MULT = 16;             // input channels per LDS stage of the widest configuration
+
+struct WinoParams {
+    const float* x;        // [B][H][W][Cin]
+    const float* u;        // [Cin][4][Cout][4]
+    const float* bias;     // [Cout] or null
+    float* y;              // [B][H][W][Cout]
+    float* stats;          // null, or [G][2][Cout] += sum / sum of squares of the raw output (BatchNorm statistics)
+    int B, H, W, Cin, Cout;
+    int tiles_x, tiles_y;  // channel blocks, tile blocks (set by the launcher)
+    int relu;
+    int stat_split;        // images [0, stat_split) -> group 0, the rest -> group 1 (0x7fffffff: one group)
+};
+
+// w [Cout][3][3][Cin] -> u [Cin][4][Cout][4] (flip = 0), or the data-gradient filter: u [Cout][4][Cin][4] from w rotated 180 degrees
+__global__ __launch_bounds__(NT) void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin,
+                                                          int flip) {
+    const int n = Cout * Cin;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < n; i += gridDim.x * NT) {
+        const int co = i / Cin, ci = i - co * Cin;
+        float g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                g[ky][kx] = w[((size_t)co * 9 + (flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx)) * Cin + ci];
+        float t[4][3];     // G g
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            t[0][kx] = g[0][kx];
+            t[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+            t[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+            t[3][kx] = g[2][kx];
+        }
+        // (G g) G^T ; K = reduction channel of the GEMM, N = output channel; component row a of (K, N) at [K][a][N] as one float4
+        const int K = flip ? co : ci, N = flip ? ci : co, NN = flip ? Cin : Cout;
+        f32x4* out = reinterpret_cast<f32x4*>(u) + (size_t)K * 4 * NN + N;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            out[(size_t)a * NN] = f32x4{t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+    }
+}
+
+// One launch for all the weights of a network (dp.FusedAdam calls it after the Adam kernel): entry = one weight, both
+// orientations; a workgroup transforms 256 (output channel, input channel) pairs of one entry.
+struct WinoEntry {
+    const float* w;    // [Cout][3][3][Cin]
+    float* u;          // forward operand   [Cin][4][Cout][4]
+    float* uf;         // data-gradient operand [Cout][4][Cin][4]
+    int Cout, Cin, wg_begin, pad_;
+};
+__device__ __forceinline__ void wino_g(const float (&g)[3][3], f32x4 (&out)[4]) {
+    float t[4][3];     // G g
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        t[0][kx] = g[0][kx];
+        t[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+        t[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+        t[3][kx] = g[2][kx];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)     // (G g) G^T
+        out[a] = f32x4{t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+}
+__global__ __launch_bounds__(NT) void wino_weights_batch_kernel(const WinoEntry* __restrict__ tab, int n) {
+    __shared__ int s_e;
+    if (threadIdx.x == 0) {
+        int e = 0;
+        while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].wg_begin) ++e;
+        s_e = e;
+    }
+    __syncthreads();
+    const WinoEntry en = tab[s_e];
+    const int i = (blockIdx.x - en.wg_begin) * NT + threadIdx.x;
+    if (i >= en.Cout * en.Cin) return;
+    const int co = i / en.Cin, ci = i - co * en.Cin;
+    float g[3][3], gr[3][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            g[ky][kx] = en.w[((size_t)co * 9 + ky * 3 + kx) * en.Cin + ci];
+            gr[2 - ky][2 - kx] = g[ky][kx];
+        }
+    f32x4 o[4];
+    wino_g(g, o);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) reinterpret_cast<f32x4*>(en.u)[((size_t)ci * 4 + a) * en.Cout + co] = o[a];
+    wino_g(gr, o);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) reinterpret_cast<f32x4*>(en.uf)[((size_t)co * 4 + a) * en.Cin + ci] = o[a];
+}
+
+// Workgroup = 4 waves = WT tile groups x WC channel groups; a wave owns 32 tiles (linear tile index over batch, tile row, tile
+// column -- no padding of the image to a block shape) x 32 output channels x all 16 components.  Per chunk of CK = 8 input channels
+// the workgroup transforms its tiles ONCE (thread = one tile x VEC channels: 16 buffer loads, out-of-image pixels come back as
+// zeros from the buffer bounds check) into sV[xi][tile][channel]; every wave then reads its A operands as one b128 per component
+// (four k-steps per read; the tile stride of CK + 4 floats keeps the eight lanes of a read group on distinct banks).  Lane half h
+// works on channels [4h, 4h + 4) of the chunk, for A and B alike.
+// Software pipeline, one barrier per chunk c: | LDS read of chunk c+1's A operands | k-steps 0..3 of chunk c, with the transform +
+// LDS write of chunk c+2 spread over them and the global loads of chunk c+3 issued in k-step 0 (a whole chunk ahead of their use) | barrier |.
+// Three LDS buffers: the one written in chunk c was last read two barriers ago.
+template <int WT, int WC, int DBG = 0>     // DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
+__global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
+    static_assert(WT * WC == 4 && (WT == 1 || WT == 2), "four waves");
+    constexpr int MT = 32 * WT, CK = 8, CKP = CK + 4, KH = 4, VEC = WT, PP = CK / VEC;
+    static_assert(MT * PP == NT, "one staging item per thread");
+    __shared__ __attribute__((aligned(16))) float sV[3][16][MT][CKP];
+    __shared__ int sT[MT];
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wt = wave / WC, wc = wave % WC;
+    const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+    const int TXn = (W + 1) >> 1, TYn = (H + 1) >> 1, ntiles = p.B * TYn * TXn;
+    // XCD-aware order: workgroups that share input tiles (the channel blocks of one tile block) run on the same XCD / L2
+    const int nb = p.tiles_x, ntb = p.tiles_y;                        // channel blocks, tile blocks
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cb = slot % nb, tb = (slot / nb) * 8 + xcd;
+    if (tb >= ntb) return;
+    const int tile0 = tb * MT;
+    const int co = cb * 32 * WC + wc * 32 + r;                        // my output channel
+    const bool co_ok = co < Cout;
+    const int coc = min(co, Cout - 1);
+
+    auto tile_coords = [&](int t, int& bb, int& ty, int& tx) {
+        bb = t / (TYn * TXn);
+        const int rem = t - bb * (TYn * TXn);
+        ty = rem / TXn;
+        tx = rem - ty * TXn;
+    };
+    if (tid < MT) {
+        const int t = tile0 + tid;
+        int bb, ty, tx;
+        tile_coords(min(t, ntiles - 1), bb, ty, tx);
+        // first output pixel of the tile * 8 + flags (1: second row exists, 2: second column exists, 4: statistics group 1)
+        sT[tid] = t < ntiles ? (((bb * H + 2 * ty) * W + 2 * tx) << 3) | (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0) |
+                                   (bb >= p.stat_split ? 4 : 0)
+                             : -1;
+    }
+    // ---- my staging item: tile st_tile, channels [VEC st_c, VEC st_c + VEC) of each chunk; byte offsets of its 16 patch pixels
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * Cin * 4), 0x00020000);
+    const int st_tile = tid / PP, st_c = tid % PP;
+    unsigned st_off[4][4];       // 0xC0000000 = outside the image (or no such tile): the load returns zeros
+    {
+        const int t = tile0 + st_tile;
+        int bb, ty, tx;
+        tile_coords(min(t, ntiles - 1), bb, ty, tx);
+        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = t < ntiles && (unsigned)(iy0 + i) < (unsigned)H && (unsigned)(ix0 + j) < (unsigned)W;
+                st_off[i][j] = ok ? (unsigned)((((bb * H + iy0 + i) * W + ix0 + j) * Cin + VEC * st_c) * 4) : 0xC0000000u;
+            }
+    }
+    using vec_t = typename std::conditional<VEC == 2, f32x2, float>::type;
+    auto load_stage = [&](int chunk, vec_t (&d)[4][4]) {
+        const int soff = chunk * CK * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (VEC == 2) {
+                    d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, st_off[i][j], soff, 0));
+                } else {
+                    d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, st_off[i][j], soff, 0));
+                }
+            }
+    };
+    auto load_stage_part = [&](int chunk, vec_t (&d)[4][4], int part) {       // part 0: pixels 0..5, 1: 6..10, 2: 11..15
+        const int soff = chunk * CK * 4;
+        const int lo = part == 0 ? 0 : part == 1 ? 6 : 11, hi = part == 0 ? 6 : part == 1 ? 11 : 16;
+#pragma unroll
+        for (int e = lo; e < hi; ++e) {
+            const int i = e >> 2, j = e & 3;
+            if constexpr (VEC == 2) {
+                d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, st_off[i][j], soff, 0));
+            } else {
+                d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, st_off[i][j], soff, 0));
+            }
+        }
+    };
+    // transform in four pieces (one per k-step): piece 0 = B^T d, piece k = row k of (B^T d) B and its four LDS writes ... rows 0..3
+    // are split 1 + 1 + 1 + 1 with the column transform in front of row 0
+    auto transform_piece = [&](int piece, int buf, const vec_t (&d)[4][4], vec_t (&t)[4][4]) {
+        if (piece == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // B^T d
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+        }
+        const int i = piece;                              // (B^T d) B, row i
+        float* o = &sV[buf][4 * i][st_tile][VEC * st_c];
+        *reinterpret_cast<vec_t*>(o) = t[i][0] - t[i][2];
+        *reinterpret_cast<vec_t*>(o + MT * CKP) = t[i][1] + t[i][2];
+        *reinterpret_cast<vec_t*>(o + 2 * MT * CKP) = t[i][2] - t[i][1];
+        *reinterpret_cast<vec_t*>(o + 3 * MT * CKP) = t[i][1] - t[i][3];
+    };
+
+    // ---- B operands: u [K][4][N] of float4; my channel of k-step j of chunk c is 8 c + 4 h + j
+    const __amdgpu_buffer_rsrc_t ur =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, (int)((size_t)Cin * Cout * 64), 0x00020000);
+    const unsigned u_voff = (unsigned)(((size_t)h * KH * 4 * Cout + coc) * 16);
+    const int u_kstride = 4 * Cout * 16, u_qstride = Cout * 16;       // bytes per channel, per component row
+    f32x4 un[4];
+    auto load_u = [&](int chunk, int j) {
+        const int soff = (chunk * CK + j) * u_kstride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // (bit_cast of the builtin's own vector type: an implicit conversion to an ext_vector_type splats element 0)
+            un[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, u_voff, soff + q * u_qstride, 0));
+        }
+    };
+    load_u(0, 0);
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+
+    const int nchunk = Cin / CK;
+    vec_t stg[4][4], tt[4][4];
+    f32x4 a[16], an[16];
+    auto read_a = [&](int buf, f32x4 (&dst)[16]) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[q] = *reinterpret_cast<const f32x4*>(&sV[buf][q][32 * wt + r][h * KH]);
+    };
+    // prologue: chunks 0 and 1 into buffers 0 and 1 (both loads in flight together), chunk 2 loaded (chunks past the end
+    // re-read the last one; never used)
+    {
+        vec_t stg1[4][4];
+        load_stage(0, stg);
+        load_stage(1, stg1);                              // nchunk >= 2
+#pragma unroll
+        for (int k = 0; k < 4; ++k) transform_piece(k, 0, stg, tt);
+        load_stage(min(2, nchunk - 1), stg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) transform_piece(k, 1, stg1, tt);
+    }
+    __syncthreads();
+    read_a(0, a);
+
+    // one chunk: MFMAs of chunk ch from `ac`; `anx` <- A operands of chunk ch + 1.  Every k-step is one scheduling region in which
+    // the next k-step's B operands, a quarter of the A reads, a transform piece and a third of the stage loads are interleaved
+    // with the 16 MFMAs (one memory instruction behind each of the first MFMAs, B operands first: they are needed soonest).
+    int bnext = 1, bwrite = 2;                             // buffers of chunk ch + 1 (to read) and ch + 2 (to write)
+    auto chunk_body = [&](int ch, f32x4 (&ac)[16], f32x4 (&anx)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            float uc[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) uc[q] = un[q >> 2][q & 3];
+            if (!(DBG & 1)) {
+                if (j < 3) load_u(ch, j + 1);
+                else load_u(min(ch + 1, nchunk - 1), 0);   // after the last chunk: a re-read, never used
+            }
+            if (!(DBG & 2)) {
+#pragma unroll
+                for (int q = 4 * j; q < 4 * j + 4; ++q)
+                    anx[q] = *reinterpret_cast<const f32x4*>(&sV[bnext][q][32 * wt + r][h * KH]);
+            }
+            if (!(DBG & 4)) {
+                transform_piece(j, bwrite, stg, tt);
+                // stg is free once piece 0 has formed B^T d: the loads of chunk ch + 3 follow in k-steps 0..2 (6 + 5 + 5)
+                if (j < 3) load_stage_part(min(ch + 3, nchunk - 1), stg, j);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[q][j], uc[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(DBG & 8)) __syncthreads();
+        const int bfree = bnext == 0 ? 2 : bnext - 1;      // (ch mod 3): read during the previous chunk
+        bnext = bwrite;
+        bwrite = bfree;
+    };
+    for (int ch = 0; ch < nchunk; ch += 2) {               // Cin % 16 == 0: an even number of chunks
+        chunk_body(ch, a, an);
+        chunk_body(ch + 1, an, a);
+    }
+
+    // ---- output transform, bias / ReLU / statistics, store: reg i <-> tile m = (i & 3) + 8 (i >> 2) + 4 h of my channel
+    if (DBG & 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += acc[q][i];
+        if (co_ok && sum == 123.f) p.y[co] = sum;
+        return;
+    }
+    // Branch-free: an output that does not exist (tile past the end, odd H / W, channel past Cout) gets a buffer offset beyond
+    // the tensor and the store is dropped by the bounds check; tiles are processed in register pairs (packed fp32 adds).
+    const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    const bool want_stats = p.stats != nullptr;
+    int tinfo[16];
+    unsigned tbase[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tinfo[i] = sT[32 * wt + (i & 3) + 8 * (i >> 2) + 4 * h];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tbase[i] = ((unsigned)(tinfo[i] >> 3) * Cout + co) * 4u;
+    float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+    const unsigned row_b = (unsigned)W * Cout * 4, col_b = (unsigned)Cout * 4;
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) {
+        const int i = 2 * ip;
+        f32x2 s[2][4], y[2][2];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {                  // A^T M
+            const f32x2 m0{acc[0 + bq][i], acc[0 + bq][i + 1]}, m1{acc[4 + bq][i], acc[4 + bq][i + 1]};
+            const f32x2 m2{acc[8 + bq][i], acc[8 + bq][i + 1]}, m3{acc[12 + bq][i], acc[12 + bq][i + 1]};
+            s[0][bq] = m0 + m1 + m2;
+            s[1][bq] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {                  // (A^T M) A
+            y[a2][0] = s[a2][0] + s[a2][1] + s[a2][2];
+            y[a2][1] = s[a2][1] - s[a2][2] - s[a2][3];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int info = tinfo[i + e];
+            const bool ok = (info >= 0) & co_ok;
+            const unsigned base = tbase[i + e];
+            const bool okr = ok & ((info & 1) != 0), okc = ok & ((info & 2) != 0), okrc = okr & okc;
+            const bool v[2][2] = {{ok, okc}, {okr, okrc}};
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const float yv = y[a2][c2][e];
+                    const unsigned off = v[a2][c2] ? base + a2 * row_b + c2 * col_b : 0xC0000000u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(yv + bv, lo)), yr, off, 0, 0);
+                }
+            if (want_stats) {
+                float ls = 0.f, lq = 0.f;
+#pragma unroll
+                for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const float yv = v[a2][c2] ? y[a2][c2][e] : 0.f;
+                        ls += yv;
+                        lq += yv * yv;
+                    }
+                const bool g1 = info & 4;
+                ssum[0] += g1 ? 0.f : ls;
+                ssq[0] += g1 ? 0.f : lq;
+                ssum[1] += g1 ? ls : 0.f;
+                ssq[1] += g1 ? lq : 0.f;
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float a2 = ssum[g] + __shfl_xor(ssum[g], 32, 64), q2 = ssq[g] + __shfl_xor(ssq[g], 32, 64);
+            if (h == 0 && co_ok && (a2 != 0.f || q2 != 0.f)) {
+                atomicAdd(p.stats + g * 2 * Cout + co, a2);
+                atomicAdd(p.stats + g * 2 * Cout + Cout + co, q2);
+            }
+        }
+    }
+}
+
+template <int WT, int WC>
+void launch_wino(WinoParams& p, hipStream_t st) {
+    const int ntiles = p.B * ((p.H + 1) / 2) * ((p.W + 1) / 2);
+    p.tiles_x = (p.Cout + 32 * WC - 1) / (32 * WC);       // channel blocks
+    p.tiles_y = (ntiles + 32 * WT - 1) / (32 * WT);       // tile blocks
+    const size_t grid = (size_t)((p.tiles_y + 7) / 8) * 8 * p.tiles_x;
+    static const int dbg = getenv("DVS_WINO_DBG") ? atoi(getenv("DVS_WINO_DBG")) : 0;
+#define WINO_DBG_CASE(D) \
+    case D: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, D>), dim3((unsigned)grid), dim3(NT), 0, st, p); break;
+    switch (dbg) {
+        WINO_DBG_CASE(1) WINO_DBG_CASE(2) WINO_DBG_CASE(4) WINO_DBG_CASE(8) WINO_DBG_CASE(15) WINO_DBG_CASE(16) WINO_DBG_CASE(31)
+        default: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC>), dim3((unsigned)grid), dim3(NT), 0, st, p);
+    }
+#undef WINO_DBG_CASE
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_wino_weights(const float* w, float* u, int Cout, int Cin, int flip, void* stream) {
+    DVS_REQUIRE(w && u && Cout > 0 && Cin > 0, "dvs_wino_weights: bad argument");
+    int blocks = (Cout * Cin + NT - 1) / NT;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3(blocks), dim3(NT), 0, static_cast<hipStream_t>(stream), w, u, Cout, Cin, flip);
+    return dvs::check_launch("dvs_wino_weights");
+}
+
+int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream) {
+    DVS_REQUIRE(table && n_entries > 0 && total_workgroups > 0, "dvs_wino_weights_batch: bad argument");
+    hipLaunchKernelGGL(wino_weights_batch_kernel, dim3(total_workgroups), dim3(NT), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const WinoEntry*>(table), n_entries);
+    return dvs::check_launch("dvs_wino_weights_batch");
+}
+
+int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* stats, int stat_groups, int B, int H,
+                         int W, int Cin, int Cout, int relu, int as_dgrad, void* stream) {
+    DVS_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_wino_fwd: bad argument");
+    DVS_REQUIRE(Cin % CIN_MULT == 0 && (Cout & 3) == 0, "dvs_conv3x3_wino_fwd: Cin %% 16 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
+    DVS_REQUIRE(stat_groups >= 0 && stat_groups <= 2 && (stat_groups != 2 || (B & 1) == 0), "dvs_conv3x3_wino_fwd: stat_groups");
+    DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
+                "dvs_conv3x3_wino_fwd: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    WinoParams p{x, u, bias, y, stats, B, H, W, Cin, Cout, 0, 0, relu, stat_groups == 2 ? B / 2 : 0x7fffffff};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
+    prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
+    if (Cout > 64) launch_wino<1, 4>(p, st);
+    else launch_wino<2, 2>(p, st);
+    return dvs::check_launch("dvs_conv3x3_wino_fwd");
+}
+
+}  // extern "C"

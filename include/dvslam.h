@@ -133,6 +133,20 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *                       carries the forward's input-side fusion (x2/C1, in_scale/in_shift/in_relu,
  *                       nchw_planar; act/stats ignored).  With nchw_planar dw is packed [Cout][Cin][kh][8].
  *   Channel counts must be multiples of 4 (NHWC 16-byte gathers). */
+/* Winograd F(2x2, 3x3) for the stride-1 / pad-1 3x3 convolutions of the ResNet BasicBlocks (torchvision BasicBlock conv1/conv2
+ * as used by model/resnet_encoder.py:94-111): 16 products per 2x2 outputs instead of 36 on the fp32 matrix cores.
+ *   dvs_wino_weights:     u [K][4][N][4] = G g G^T of every (input, output) channel pair of w [Cout][3][3][Cin];
+ *                         flip = 0: K = Cin, N = Cout (forward); flip = 1: K = Cout, N = Cin, filter rotated by 180 degrees (the
+ *                         data gradient of the same convolution is dvs_conv3x3_wino_fwd(dy, u_flip) with Cin/Cout swapped).
+ *   dvs_wino_weights_batch: both orientations of n weights in one launch; table rows {w, u, u_flip (pointers), Cout, Cin,
+ *                         first workgroup, 0 (int32)} sorted by first workgroup, ceil(Cout*Cin/256) workgroups per entry.
+ *   dvs_conv3x3_wino_fwd: y [B,H,W,Cout] = [relu](conv3x3(x [B,H,W,Cin]) + bias); stats (NULL = skip) [stat_groups][2][Cout] +=
+ *                         per-channel sum / sum of squares of the raw output, as dvs_conv2d_fwd's epilogue does.  Cin % 16 == 0,
+ *                         Cout % 4 == 0, tensors < 2 GiB.  as_dgrad: count the launch in the data-gradient profile slot. */
+int dvs_wino_weights(const float* w, float* u, int Cout, int Cin, int flip, void* stream);
+int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
+int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* stats, int stat_groups, int B, int H,
+                         int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
 /*   dvs_conv2d_pack_wt_batch: the same transpose for many weights in one launch.  `table` (device memory) = n_entries
  *   records { const float* w; float* wt; int Cout, Cin, taps, wg_begin; } (32 bytes each), wg_begin = number of

@@ -1,0 +1,133 @@
+"""Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip; torchvision BasicBlock conv1/conv2 as used by model/resnet_encoder.py:94-111)
+against F.conv2d in fp64: forward with the BatchNorm statistics epilogue, the data gradient through the rotated filter, the
+batched weight transform, odd / tiny images and ragged channel blocks, and the autograd path of conv.conv2d that selects it."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+TOL = 3e-6        # max |err| / max |ref|; the direct kernel and MIOpen sit at 1-4e-6 on the same shapes (tools/wino_bench.py)
+
+
+def _mk(B, ci, co, h, w, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(B, ci, h, w, device="cuda", generator=g).contiguous(memory_format=CL)
+    wt = (torch.randn(co, ci, 3, 3, device="cuda", generator=g) * (2.0 / (ci * 9)) ** 0.5).contiguous(memory_format=CL)
+    return x, wt
+
+
+def _rel(a, ref):
+    return float((a.double() - ref).abs().max() / ref.abs().max())
+
+
+SHAPES = [(2, 64, 64, 120, 160), (2, 128, 128, 60, 80), (2, 256, 256, 30, 40), (2, 512, 512, 15, 20),      # encoder, 480x640
+          (4, 64, 128, 13, 27), (2, 128, 64, 1, 5), (2, 64, 192, 7, 1), (6, 80, 96, 6, 6), (1, 64, 64, 2, 2)]
+
+
+@pytest.mark.parametrize("B,ci,co,h,w", SHAPES)
+def test_forward_stats_and_data_gradient(B, ci, co, h, w):
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(B, ci, co, h, w)
+    y64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    for groups in (1, 2) if B % 2 == 0 else (1,):
+        st = torch.zeros((2, co) if groups == 1 else (2, 2, co), device="cuda")
+        y = DC.conv3x3_wino(x, wt, st, groups)
+        assert y.shape == y64.shape and y.is_contiguous(memory_format=CL)
+        assert _rel(y, y64) < TOL
+        parts = [y64] if groups == 1 else [y64[: B // 2], y64[B // 2:]]
+        ref = torch.stack([torch.stack([p.sum((0, 2, 3)), (p * p).sum((0, 2, 3))]) for p in parts])
+        ref = ref[0] if groups == 1 else ref
+        assert float((st.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+    dy = torch.randn(B, co, h, w, device="cuda").contiguous(memory_format=CL)
+    dx64 = F.conv_transpose2d(dy.double(), wt.double(), None, 1, 1)
+    dx = DC.conv3x3_wino(dy, wt, flip=True)
+    assert dx.shape == x.shape and _rel(dx, dx64) < TOL
+
+
+def test_batched_weight_transform_matches_the_single_launches():
+    from deep_visual_slam_amd import conv as DC
+    ws = [_mk(1, ci, co, 2, 2, seed=s)[1] for s, (ci, co) in enumerate([(64, 64), (64, 128), (128, 128), (512, 256)])]
+    ws.append(torch.randn(32, 16, 3, 3, device="cuda").contiguous(memory_format=CL))          # not eligible: left alone
+    ref = [(DC._wino_weight(w, w, False).clone(), DC._wino_weight(w, w, True).clone()) for w in ws[:4]]
+    DC._wino_packed.clear()
+    pk = DC.PackedWeights(ws)
+    assert len(pk.wino) == 4
+    pk.repack()
+    try:
+        for w, (u, uf) in zip(ws[:4], ref):
+            ent = DC._wino_packed[w.data_ptr()]
+            assert torch.equal(ent[0], u) and torch.equal(ent[1], uf)
+            assert DC._wino_weight(w, w, False) is ent[0]
+    finally:
+        pk.release()
+    assert not DC._wino_packed
+
+
+def test_operand_follows_the_weight():
+    """An in-place weight update (any optimiser) bumps the version counter: the cached operand must not be served again."""
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(2, 64, 64, 8, 8)
+    y0 = DC.conv3x3_wino(x, wt)
+    with torch.no_grad():
+        wt.mul_(2.0)
+    y1 = DC.conv3x3_wino(x, wt)
+    assert _rel(y1, 2.0 * y0.double()) < 1e-6
+
+
+def test_same_shaped_weights_in_standard_layout_do_not_share_an_operand():
+    """Weights that are not stored channels-last are copied to NHWC per call; the copies of two different weights can get the
+    same address from the allocator, so the operand cache must be keyed by the weight itself."""
+    from deep_visual_slam_amd import conv as DC
+    x, _ = _mk(2, 64, 64, 8, 8)
+    ws = [torch.randn(64, 64, 3, 3, device="cuda") * 0.05 for _ in range(4)]          # standard (NCHW-contiguous) layout
+    for w in ws:
+        y = DC.conv3x3_wino(x, w)
+        assert _rel(y, F.conv2d(x.double(), w.double(), None, 1, 1)) < TOL
+
+
+def test_operand_cache_is_pinned_to_the_weight_object():
+    """A live parameter whose storage moved (an arena, .to()) leaves its old address to the allocator; an entry filed under
+    that address for the OLD owner must not serve the new tenant even when version counter and shape agree."""
+    import weakref
+    from deep_visual_slam_amd import conv as DC
+    x, wa = _mk(2, 64, 64, 8, 8, seed=1)
+    _, wb = _mk(2, 64, 64, 8, 8, seed=2)
+    ua = DC._wino_weight(wa, wa, False)
+    DC._wino_packed[wb.data_ptr()] = [ua, None, wb._version, tuple(wb.shape), weakref.ref(wa)]     # what a moved `wa` leaves behind
+    y = DC.conv3x3_wino(x, wb)
+    assert _rel(y, F.conv2d(x.double(), wb.double(), None, 1, 1)) < TOL
+
+
+def test_autograd_path_selects_it_and_matches_torch():
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(4, 64, 128, 24, 32)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    assert DC.wino_eligible(wt, 1, 1, False, None, None, False, None)
+    y, st = DC.conv2d(x, wt, None, 1, 1, want_stats=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    x64, w64 = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(gy.double())
+    assert _rel(y, y64.detach()) < TOL and _rel(x.grad, x64.grad) < TOL and _rel(wt.grad, w64.grad) < 2e-5
+    assert float((st[0].double() - y64.detach().sum((0, 2, 3))).abs().max() / y64.detach().sum((0, 2, 3)).abs().max()) < 2e-5
+    # the switch: DVS_WINOGRAD=0 keeps every convolution on the direct kernels
+    old, DC._WINO = DC._WINO, False
+    try:
+        assert not DC.wino_eligible(wt, 1, 1, False, None, None, False, None)
+        y2 = DC.conv2d(x.detach(), wt.detach(), None, 1, 1)
+    finally:
+        DC._WINO = old
+    assert _rel(y2, y64.detach()) < 6e-6
+
+
+def test_rejects_what_it_does_not_cover():
+    from deep_visual_slam_amd import _lib, conv as DC
+    x, wt = _mk(1, 24, 64, 4, 4)
+    with pytest.raises(_lib.DvsError):
+        DC.conv3x3_wino(x, wt)                         # Cin % 16 != 0
+    x, wt = _mk(1, 64, 64, 4, 4)
+    with pytest.raises(_lib.DvsError):
+        DC.conv3x3_wino(x[:, :32], wt)                 # channel mismatch
