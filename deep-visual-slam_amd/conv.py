@@ -256,6 +256,32 @@ def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False):
     return y
 
 
+_WINO_WGRAD = os.environ.get("DVS_WINOGRAD_WGRAD", "1") != "0"
+_WINO_WGS = int(os.environ.get("DVS_WINO_WGRAD_WGS", "0"))
+
+
+def wino_wgrad_eligible(weight_shape):
+    co, ci = weight_shape[:2]
+    return _WINO_WGRAD and co % 32 == 0 and ci % 32 == 0
+
+
+def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
+    """Weight gradient of the stride-1 / pad-1 3x3 convolution on the Winograd kernel.  dw_out: gradient sink to add into
+    (returns None), else a zero-filled [Cout][kh][kw][Cin]-stored tensor of the weight's shape is returned."""
+    x, dy = _nhwc(x), _nhwc(dy)
+    co, ci = weight_shape[:2]
+    B, _, H, W = x.shape
+    if dw_out is not None:
+        if tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
+            raise _lib.DvsError("conv3x3_wino_wgrad: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
+        dw = dw_out
+    else:
+        dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
+    check(_lib.lib().dvs_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ci, co, _WINO_WGS,
+                                            _lib.stream()), "dvs_conv3x3_wino_wgrad")
+    return None if dw_out is not None else dw
+
+
 def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False):
     """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
     split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
@@ -419,9 +445,12 @@ class _Conv2d(torch.autograd.Function):
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, torch.cuda.current_stream())
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
-                dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
-                                      in_scale=scale, in_shift=shift, nchw_planar=planar,
-                                      pooled=_has_grad(weight), dw_out=wsink, db_out=bsink_w)
+                if ctx.wino and wino_wgrad_eligible(weight.shape):
+                    dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
+                else:
+                    dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
+                                          in_scale=scale, in_shift=shift, nchw_planar=planar,
+                                          pooled=_has_grad(weight), dw_out=wsink, db_out=bsink_w)
                 if pre_db is not None and pre_db is not True:
                     db = pre_db
             else:
@@ -430,8 +459,11 @@ class _Conv2d(torch.autograd.Function):
                 gradsink.note(ctx.bias_ref, cur, side)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
-                                 in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink_w)
+                    if ctx.wino and wino_wgrad_eligible(weight.shape):
+                        conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
+                    else:
+                        conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
+                                     in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink_w)
                 for t in (x, dy, y, x2):
                     if isinstance(t, torch.Tensor):
                         t.record_stream(side)                # keep the allocator from recycling them under the kernel

@@ -403,6 +403,226 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     }
 }
 
+// ---- weight gradient:  dL/dg = G^T [ sum over tiles (A dY A^T) o (B^T d B) ] G  (the same bilinear form read for g) ------------
+// 16 GEMMs dU_xi [Cout x Cin] = sum_tiles P_xi[tile][co] * V_xi[tile][ci] with K = tiles.  A wave owns a 32 x 32 block of
+// (output channel, input channel) pairs for all 16 components (256 accumulator registers) and a range of tiles; both operands are
+// transformed in-lane from global memory (lane = one channel of one tile: 4 dY values -> 16, 4 x 4 input values -> 16; all loads
+// are dword buffer loads that are contiguous over the 32 channels of a half wave; out-of-image pixels come back as zeros from the
+// buffer bounds check).  No LDS and no barrier in the loop.  Three-stage software pipeline per k-step k: the loads of k+2 are
+// issued, the operands of k+1 are transformed and the offsets of k+3 computed between the MFMAs of k -- none of that vector work
+// depends on the MFMAs it is interleaved with.  The four waves of a workgroup split the workgroup's tile range and add their
+// accumulators through LDS; the first wave applies G^T . G in-lane (all 16 components of a (co, ci) pair sit in one lane) and
+// adds the 3 x 3 results into dw -- plain adds when the tile range is not split over workgroups, float atomics otherwise.
+struct WinoWgradParams {
+    const float* x;        // [B][H][W][Cin]
+    const float* dy;       // [B][H][W][Cout]
+    float* dw;             // [Cout][3][3][Cin], +=
+    int B, H, W, Cin, Cout;
+    int nblk_ci, nblk;     // 32-channel blocks of Cin; blocks of (Cout, Cin)
+    int S;                 // splits of the tile range over workgroups
+    int tiles_per_wg;      // multiple of 16
+};
+
+__global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
+    __shared__ float sR[2][256][64];                      // 128 KB: accumulators of two waves during the reduction
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+    const int TXn = (W + 1) >> 1, TYn = (H + 1) >> 1, ntiles = p.B * TYn * TXn;
+    // workgroups of one XCD walk the channel blocks of the same tile range first (its x / dY stay in that L2); with fewer than
+    // eight tile ranges (S = 1, 2 or 4) 8 / S XCDs share a range and deal its channel blocks between them
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int blk, sp;
+    if (p.S >= 8) {
+        blk = slot % p.nblk;
+        sp = (slot / p.nblk) * 8 + xcd;
+    } else {
+        sp = xcd % p.S;
+        blk = slot * (8 / p.S) + xcd / p.S;
+    }
+    if (sp >= p.S || blk >= p.nblk) return;
+    const int co0 = (blk / p.nblk_ci) * 32, ci0 = (blk % p.nblk_ci) * 32;
+    const int per_wave = p.tiles_per_wg >> 2;              // multiple of 4: an even number of k-steps
+    const int t_begin = sp * p.tiles_per_wg + wave * per_wave;
+    const int t_end = min(t_begin + per_wave, ntiles);
+    const int ksteps = t_begin < ntiles ? per_wave >> 1 : 0;
+
+    // the x resource starts (W + 1) pixels before the tensor so that patch offsets are non-negative: pixel (i, j) of the patch of
+    // a tile whose first output pixel has index pb is at pb + (i - 1) W + (j - 1); reads in front of the tensor are masked out
+    const size_t lead = (size_t)(W + 1) * Cin * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)((size_t)p.B * H * W * Cin * 4 + lead), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    constexpr unsigned OOB = 0xC0000000u;
+
+    // my tile of k-step k: t_begin + 2 k + h
+    int t = t_begin + h, tb, ty, tx;
+    {
+        const int tc = min(t, ntiles - 1);
+        tb = tc / (TYn * TXn);
+        const int rem = tc - tb * (TYn * TXn);
+        ty = rem / TXn;
+        tx = rem - ty * TXn;
+    }
+    // offsets of the current tile's 16 + 4 loads: v | row mask | column mask, a mask being 0 (inside) or OOB (outside: the OR
+    // lands beyond every tensor < 2 GiB); then two tiles on
+    unsigned ox_[16], oy_[4];
+    auto offsets_and_advance = [&]() {
+        const int oy = 2 * ty, ox = 2 * tx;
+        const unsigned pb = (unsigned)((tb * H + oy) * W + ox);
+        const unsigned vx = (pb * Cin + ci0 + r) * 4u, vy = (pb * Cout + co0 + r) * 4u;
+        const unsigned dead = t < t_end ? 0u : OOB;
+        const unsigned rm[4] = {oy >= 1 ? dead : OOB, dead, oy + 1 < H ? dead : OOB, oy + 2 < H ? dead : OOB};
+        const unsigned cm[4] = {ox >= 1 ? 0u : OOB, 0u, ox + 1 < W ? 0u : OOB, ox + 2 < W ? 0u : OOB};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ox_[4 * i + j] = vx | rm[i] | cm[j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) oy_[2 * i + j] = vy | rm[1 + i] | cm[1 + j];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            ++tx;
+            const bool wx = tx == TXn;
+            tx = wx ? 0 : tx;
+            ty += wx ? 1 : 0;
+            const bool wy = ty == TYn;
+            ty = wy ? 0 : ty;
+            tb += wy ? 1 : 0;
+        }
+        t += 2;
+    };
+    auto issue_loads = [&](float (&xd)[16], float (&yd)[4]) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], ((e >> 2) * W + (e & 3)) * Cin * 4, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            yd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
+    };
+    auto transform = [&](const float (&xc)[16], const float (&yc)[4], float (&v)[16], float (&pm)[16]) {
+        float tt[4][4], pr[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                     // B^T d
+            tt[0][j] = xc[j] - xc[8 + j];
+            tt[1][j] = xc[4 + j] + xc[8 + j];
+            tt[2][j] = xc[8 + j] - xc[4 + j];
+            tt[3][j] = xc[4 + j] - xc[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                     // (B^T d) B
+            v[4 * i + 0] = tt[i][0] - tt[i][2];
+            v[4 * i + 1] = tt[i][1] + tt[i][2];
+            v[4 * i + 2] = tt[i][2] - tt[i][1];
+            v[4 * i + 3] = tt[i][1] - tt[i][3];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                     // A dY: rows (1,0), (1,1), (1,-1), (0,-1)
+            pr[0][j] = yc[j];
+            pr[1][j] = yc[j] + yc[2 + j];
+            pr[2][j] = yc[j] - yc[2 + j];
+            pr[3][j] = -yc[2 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                     // (A dY) A^T
+            pm[4 * i + 0] = pr[i][0];
+            pm[4 * i + 1] = pr[i][0] + pr[i][1];
+            pm[4 * i + 2] = pr[i][0] - pr[i][1];
+            pm[4 * i + 3] = -pr[i][1];
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+
+    // step k: loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from (vc, pc); (vn, pn) <- transform of rn (k+1)
+    auto kstep = [&](float (&rlx)[16], float (&rly)[4], const float (&rnx)[16], const float (&rny)[4], const float (&vc)[16],
+                     const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_loads(rlx, rly);
+        __builtin_amdgcn_sched_barrier(0);
+        transform(rnx, rny, vn, pn);
+        offsets_and_advance();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[q], vc[q], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
+        }
+    };
+    float r0x[16], r0y[4], r1x[16], r1y[4], v0[16], p0[16], v1[16], p1[16];
+    offsets_and_advance();
+    issue_loads(r0x, r0y);                                // k-step 0
+    offsets_and_advance();
+    issue_loads(r1x, r1y);                                // k-step 1
+    offsets_and_advance();                                // offsets of k-step 2
+    transform(r0x, r0y, v0, p0);
+    for (int k = 0; k < ksteps; k += 2) {
+        kstep(r0x, r0y, r1x, r1y, v0, p0, v1, p1);
+        kstep(r1x, r1y, r0x, r0y, v1, p1, v0, p0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- add the four waves' accumulators: waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds
+    if (wave >= 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sR[wave - 2][q * 16 + i][lane] = acc[q][i];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] += sR[wave][q * 16 + i][lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sR[0][q * 16 + i][lane] = acc[q][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool exclusive = p.S == 1;                  // this workgroup alone owns its block of dw
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = (i & 3) + 8 * (i >> 2) + 4 * h;  // output channel row of the block
+            float u[4][4], t3[3][4];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) u[q >> 2][q & 3] = acc[q][i] + sR[0][q * 16 + i][lane];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {                  // G^T dU
+                const float hs = 0.5f * (u[1][b] + u[2][b]);
+                t3[0][b] = u[0][b] + hs;
+                t3[1][b] = 0.5f * (u[1][b] - u[2][b]);
+                t3[2][b] = hs + u[3][b];
+            }
+            float* o = p.dw + (size_t)(co0 + m) * 9 * Cin + ci0 + r;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {                  // (G^T dU) G
+                const float hs = 0.5f * (t3[k][1] + t3[k][2]);
+                const float w3[3] = {t3[k][0] + hs, 0.5f * (t3[k][1] - t3[k][2]), hs + t3[k][3]};
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    float* a = o + (size_t)(3 * k + l) * Cin;
+                    if (exclusive) *a += w3[l];
+                    else atomicAdd(a, w3[l]);
+                }
+            }
+        }
+    }
+}
+
 template <int WT, int WC>
 void launch_wino(WinoParams& p, hipStream_t st) {
     const int ntiles = p.B * ((p.H + 1) / 2) * ((p.W + 1) / 2);
@@ -452,6 +672,37 @@ int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, floa
     if (Cout > 64) launch_wino<1, 4>(p, st);
     else launch_wino<2, 2>(p, st);
     return dvs::check_launch("dvs_conv3x3_wino_fwd");
+}
+
+int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
+                           void* stream) {
+    DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0, "dvs_conv3x3_wino_wgrad: bad argument");
+    DVS_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_wino_wgrad: channel counts must be multiples of 32 (got %d, %d)",
+                Cin, Cout);
+    DVS_REQUIRE(((double)B * H * W + W + 1) * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0,
+                "dvs_conv3x3_wino_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
+    prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
+    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0};
+    const int ntiles = B * ((H + 1) / 2) * ((W + 1) / 2);
+    // default: one round of one workgroup per CU (fewer, longer tile ranges: less reduction and atomic traffic); the 512-channel
+    // layers take two tile ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
+    if (target_workgroups <= 0) target_workgroups = p.nblk >= 256 ? 512 : 256;
+    int S = (target_workgroups + p.nblk / 2) / p.nblk;
+    S = S < 1 ? 1 : S;
+    int tpw = ((ntiles + S - 1) / S + 15) & ~15;          // tiles per workgroup: four waves x two tiles x an even number of k-steps
+    tpw = tpw < 64 ? 64 : tpw;                             // at least eight k-steps per wave
+    S = (ntiles + tpw - 1) / tpw;
+    if (S < 8) {                                           // 1, 2 or 4 ranges (the XCD map of the kernel); ranges past the end add zeros
+        S = S >= 4 ? 4 : S >= 2 ? 2 : 1;
+        tpw = ((ntiles + S - 1) / S + 15) & ~15;
+    }
+    p.tiles_per_wg = tpw;
+    p.S = S;
+    const size_t grid = S >= 8 ? (size_t)((S + 7) / 8) * 8 * p.nblk : (size_t)((p.nblk + 8 / S - 1) / (8 / S)) * 8;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)grid), dim3(NT), 0, st, p);
+    return dvs::check_launch("dvs_conv3x3_wino_wgrad");
 }
 
 }  // extern "C"

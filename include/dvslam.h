@@ -142,8 +142,14 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *                         first workgroup, 0 (int32)} sorted by first workgroup, ceil(Cout*Cin/256) workgroups per entry.
  *   dvs_conv3x3_wino_fwd: y [B,H,W,Cout] = [relu](conv3x3(x [B,H,W,Cin]) + bias); stats (NULL = skip) [stat_groups][2][Cout] +=
  *                         per-channel sum / sum of squares of the raw output, as dvs_conv2d_fwd's epilogue does.  Cin % 16 == 0,
- *                         Cout % 4 == 0, tensors < 2 GiB.  as_dgrad: count the launch in the data-gradient profile slot. */
+ *                         Cout % 4 == 0, tensors < 2 GiB.  as_dgrad: count the launch in the data-gradient profile slot.
+ *   dvs_conv3x3_wino_wgrad: dw [Cout][3][3][Cin] += the weight gradient of that convolution from x [B,H,W,Cin] and dy [B,H,W,Cout]
+ *                         (dL/dg = G^T [sum over tiles (A dY A^T) o (B^T d B)] G), the tile range split over about
+ *                         target_workgroups (0 = default) workgroups that add into dw with float atomics (plain adds when
+ *                         one workgroup owns a block).  Cin % 32 == 0, Cout % 32 == 0, tensors < 2 GiB. */
 int dvs_wino_weights(const float* w, float* u, int Cout, int Cin, int flip, void* stream);
+int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
+                           void* stream);
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* stats, int stat_groups, int B, int H,
                          int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);

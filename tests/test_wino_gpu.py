@@ -45,6 +45,33 @@ def test_forward_stats_and_data_gradient(B, ci, co, h, w):
     assert dx.shape == x.shape and _rel(dx, dx64) < TOL
 
 
+WSHAPES = [(2, 64, 64, 120, 160), (2, 128, 128, 60, 80), (2, 256, 256, 30, 40), (2, 512, 512, 15, 20), (12, 512, 512, 15, 20),
+           (4, 64, 128, 13, 27), (2, 128, 64, 1, 5), (2, 64, 192, 7, 1), (6, 96, 96, 6, 6), (1, 64, 64, 2, 2)]
+
+
+@pytest.mark.parametrize("B,ci,co,h,w", WSHAPES)
+def test_weight_gradient(B, ci, co, h, w):
+    """dW against fp64 autograd; into a fresh tensor and accumulated into a gradient sink that already holds values; with the
+    tile range split over many workgroups (atomics) and owned by one (plain adds)."""
+    from deep_visual_slam_amd import conv as DC
+    x, _ = _mk(B, ci, co, h, w, seed=3)
+    dy = torch.randn(B, co, h, w, device="cuda").contiguous(memory_format=CL)
+    w64 = torch.zeros(co, ci, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, 1, 1).backward(dy.double())
+    ref = w64.grad
+    for wgs in (0, 1, 4096):
+        old, DC._WINO_WGS = DC._WINO_WGS, wgs
+        try:
+            dw = DC.conv3x3_wino_wgrad(x, dy, (co, ci, 3, 3))
+            assert dw.shape == ref.shape and dw.permute(0, 2, 3, 1).is_contiguous()
+            assert _rel(dw, ref) < 3e-6, wgs
+            sink = torch.full((co, ci, 3, 3), 0.5, device="cuda").contiguous(memory_format=CL)
+            assert DC.conv3x3_wino_wgrad(x, dy, (co, ci, 3, 3), dw_out=sink) is None
+            assert _rel(sink - 0.5, ref) < 3e-6 + 1e-6 / float(ref.abs().max()), wgs
+        finally:
+            DC._WINO_WGS = old
+
+
 def test_batched_weight_transform_matches_the_single_launches():
     from deep_visual_slam_amd import conv as DC
     ws = [_mk(1, ci, co, 2, 2, seed=s)[1] for s, (ci, co) in enumerate([(64, 64), (64, 128), (128, 128), (512, 256)])]

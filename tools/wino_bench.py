@@ -87,3 +87,23 @@ if os.environ.get("WINO_SWEEP"):
         for _ in range(50): go()
         e1.record(); torch.cuda.synchronize()
         print(json.dumps(dict(sweep_cin=ci, ksteps=ci // 2, us=e0.elapsed_time(e1) * 1e3 / 50)), flush=True)
+
+# weight gradient: Winograd vs the direct kernel vs fp64 autograd
+if os.environ.get("WINO_WGRAD"):
+    shapes_w = [("l1_3x3", 64, 64, 120, 160), ("l2_3x3", 128, 128, 60, 80), ("l3_3x3", 256, 256, 30, 40), ("l4_3x3", 512, 512, 15, 20),
+                ("odd", 64, 96, 13, 27)]
+    for (name, ci, co, h, w) in shapes_w:
+        x = torch.randn(B, ci, h, w, device=dev).contiguous(memory_format=CL)
+        dy = torch.randn(B, co, h, w, device=dev).contiguous(memory_format=CL)
+        w64 = torch.zeros(co, ci, 3, 3, device=dev, dtype=torch.float64, requires_grad=True)
+        F.conv2d(x.double(), w64, None, 1, 1).backward(dy.double())
+        ref = w64.grad
+        dw = DC.conv3x3_wino_wgrad(x, dy, (co, ci, 3, 3))
+        dd, _ = DC.conv2d_wgrad(x, dy, (co, ci, 3, 3), 1, 1, False, False)
+        e = lambda t: float((t.double() - ref).abs().max() / ref.abs().max())
+        sink = torch.zeros(co, ci, 3, 3, device=dev).contiguous(memory_format=CL)
+        t_w = timeit(lambda: DC.conv3x3_wino_wgrad(x, dy, (co, ci, 3, 3), dw_out=sink))
+        t_d = timeit(lambda: DC.conv2d_wgrad(x, dy, (co, ci, 3, 3), 1, 1, False, False, dw_out=sink))
+        fl = 2.0 * B * co * h * w * ci * 9
+        print(json.dumps(dict(wgrad=name, B=B, err_wino=e(dw), err_direct=e(dd), wino_ms=t_w * 1e3, wino_tf_eff=fl / t_w / 1e12,
+                              direct_ms=t_d * 1e3, direct_tf=fl / t_d / 1e12)), flush=True)
