@@ -11,9 +11,23 @@ import sys
 root, nsteps = sys.argv[1], int(sys.argv[2])
 
 
+_phase = ["fwd"]
+
+
 def family(n):
+    """Kernel name -> the profile slot bench.py counts it in.  Stateful: rows must be fed in launch order -- the Winograd kernel
+    serves the forward convolution and (on dY, with the rotated filter) the data gradient, told apart by whether the loss chain's
+    backward kernel of the step has run."""
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     base = n.split("(")[0]
+    if "chain_bwd_kernel" in n:
+        _phase[0] = "bwd"
+    elif "adam_kernel" in n:
+        _phase[0] = "fwd"
+    if "wino_wgrad" in n:
+        return "conv_wgrad_kernel"
+    if "wino_fwd_kernel" in n:
+        return "conv_dgrad_kernel" if _phase[0] == "bwd" else "conv_fwd_kernel"
     if "conv_fwd_kernel" in n or "conv_dma_kernel" in n:
         targs = base.split("<")[1].split(",") if "<" in base else []
         mode = targs[4].strip() if len(targs) > 4 else "?"
