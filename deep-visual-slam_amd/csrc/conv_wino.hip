@@ -21,6 +21,7 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int NT = 256;
+constexpr int kActRelu = 1, kActElu = 2;   // activation codes of conv_common.h (dvs_conv_fusion.act)
 constexpr int CIN_MULT = 16;             // input channels per LDS stage of the widest configuration
 
 struct WinoParams {
@@ -33,6 +34,14 @@ struct WinoParams {
     int tiles_x, tiles_y;  // channel blocks, tile blocks (set by the launcher)
     int relu;
     int stat_split;        // images [0, stat_split) -> group 0, the rest -> group 1 (0x7fffffff: one group)
+    // general gather (GEN > 0): the decoder's ReflectionPad2d(1) + [nearest 2x upsample of x (+ concat with x2)] and the
+    // full correlation of the padded-domain data gradient
+    const float* x2;       // second source, channels [C1, Cin) at full resolution, or null
+    int C1;                // channels taken from x
+    int up;                // x is [B][H/2][W/2][C1]: nearest-neighbour upsampled in the gather
+    int reflect;           // out-of-image patch pixels mirror (pad 1) instead of reading zero
+    int Ho, Wo, org;       // output size and patch origin: output tile (2ty, 2tx) reads input rows 2ty - org ... (1: 'same', 2: full)
+    int act;               // epilogue activation code of conv_common.h (0 none, 1 ReLU, 2 ELU)
 };
 
 // w [Cout][3][3][Cin] -> u [Cin][4][Cout][4] (flip = 0), or the data-gradient filter: u [Cout][4][Cin][4] from w rotated 180 degrees
@@ -123,7 +132,9 @@ __global__ __launch_bounds__(NT) void wino_weights_batch_kernel(const WinoEntry*
 // Software pipeline, one barrier per chunk c: | LDS read of chunk c+1's A operands | k-steps 0..3 of chunk c, with the transform +
 // LDS write of chunk c+2 spread over them and the global loads of chunk c+3 issued in k-step 0 (a whole chunk ahead of their use) | barrier |.
 // Three LDS buffers: the one written in chunk c was last read two barriers ago.
-template <int WT, int WC, int DBG = 0>     // DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
+// GEN: 0 = zero-padded 'same' convolution of one tensor (the BasicBlock layers); 1 = general gather from one source (reflection,
+// upsample, output size / origin); 2 = general gather from two concatenated sources.
+template <int WT, int WC, int DBG = 0, int GEN = 0>     // DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
 __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     static_assert(WT * WC == 4 && (WT == 1 || WT == 2), "four waves");
     constexpr int MT = 32 * WT, CK = 8, CKP = CK + 4, KH = 4, VEC = WT, PP = CK / VEC;
@@ -136,7 +147,8 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wt = wave / WC, wc = wave % WC;
     const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
-    const int TXn = (W + 1) >> 1, TYn = (H + 1) >> 1, ntiles = p.B * TYn * TXn;
+    const int Ho = GEN ? p.Ho : H, Wo = GEN ? p.Wo : W, org = GEN ? p.org : 1;
+    const int TXn = (Wo + 1) >> 1, TYn = (Ho + 1) >> 1, ntiles = p.B * TYn * TXn;
     // XCD-aware order: workgroups that share input tiles (the channel blocks of one tile block) run on the same XCD / L2
     const int nb = p.tiles_x, ntb = p.tiles_y;                        // channel blocks, tile blocks
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -158,54 +170,67 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         int bb, ty, tx;
         tile_coords(min(t, ntiles - 1), bb, ty, tx);
         // first output pixel of the tile * 8 + flags (1: second row exists, 2: second column exists, 4: statistics group 1)
-        sT[tid] = t < ntiles ? (((bb * H + 2 * ty) * W + 2 * tx) << 3) | (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0) |
+        sT[tid] = t < ntiles ? (((bb * Ho + 2 * ty) * Wo + 2 * tx) << 3) | (2 * ty + 1 < Ho ? 1 : 0) | (2 * tx + 1 < Wo ? 2 : 0) |
                                    (bb >= p.stat_split ? 4 : 0)
                              : -1;
     }
     // ---- my staging item: tile st_tile, channels [VEC st_c, VEC st_c + VEC) of each chunk; byte offsets of its 16 patch pixels
+    const int C1 = GEN ? p.C1 : Cin, C2 = Cin - C1;
+    const int Hs = (GEN && p.up) ? H >> 1 : H, Ws = (GEN && p.up) ? W >> 1 : W;          // geometry of source x
     const __amdgpu_buffer_rsrc_t xr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * Cin * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * Hs * Ws * C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(GEN == 2 ? p.x2 : p.x), 0, GEN == 2 ? (int)((size_t)p.B * H * W * C2 * 4) : 0, 0x00020000);
     const int st_tile = tid / PP, st_c = tid % PP;
     unsigned st_off[4][4];       // 0xC0000000 = outside the image (or no such tile): the load returns zeros
+    unsigned st_off2[GEN == 2 ? 4 : 1][GEN == 2 ? 4 : 1];
     {
         const int t = tile0 + st_tile;
         int bb, ty, tx;
         tile_coords(min(t, ntiles - 1), bb, ty, tx);
-        const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+        const int iy0 = 2 * ty - org, ix0 = 2 * tx - org;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool ok = t < ntiles && (unsigned)(iy0 + i) < (unsigned)H && (unsigned)(ix0 + j) < (unsigned)W;
-                st_off[i][j] = ok ? (unsigned)((((bb * H + iy0 + i) * W + ix0 + j) * Cin + VEC * st_c) * 4) : 0xC0000000u;
+                int iy = iy0 + i, ix = ix0 + j;
+                bool ok = t < ntiles;
+                if (GEN && p.reflect) {                   // ReflectionPad2d(1): -1 -> 1, H -> H - 2 (H, W >= 2)
+                    iy = iy < 0 ? -iy : iy >= H ? 2 * H - 2 - iy : iy;
+                    ix = ix < 0 ? -ix : ix >= W ? 2 * W - 2 - ix : ix;
+                    ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;      // (the last odd tile row / column)
+                } else {
+                    ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                }
+                const int sy = (GEN && p.up) ? iy >> 1 : iy, sx = (GEN && p.up) ? ix >> 1 : ix;
+                st_off[i][j] = ok ? (unsigned)((((bb * Hs + sy) * Ws + sx) * C1 + VEC * st_c) * 4) : 0xC0000000u;
+                if constexpr (GEN == 2) st_off2[i][j] = ok ? (unsigned)((((bb * H + iy) * W + ix) * C2 + VEC * st_c) * 4) : 0xC0000000u;
             }
     }
     using vec_t = typename std::conditional<VEC == 2, f32x2, float>::type;
+    auto load_pixel = [&](int chunk, int i, int j) -> vec_t {
+        int soff = chunk * CK * 4;
+        __amdgpu_buffer_rsrc_t rs = xr;
+        unsigned off = st_off[i][j];
+        if constexpr (GEN == 2) {                         // chunk-uniform choice of the source
+            const bool second = chunk * CK >= C1;
+            soff = second ? soff - C1 * 4 : soff;
+            rs = second ? xr2 : xr;
+            off = second ? st_off2[i][j] : off;
+        }
+        if constexpr (VEC == 2) return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, soff, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0));
+    };
     auto load_stage = [&](int chunk, vec_t (&d)[4][4]) {
-        const int soff = chunk * CK * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (VEC == 2) {
-                    d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, st_off[i][j], soff, 0));
-                } else {
-                    d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, st_off[i][j], soff, 0));
-                }
-            }
+            for (int j = 0; j < 4; ++j) d[i][j] = load_pixel(chunk, i, j);
     };
     auto load_stage_part = [&](int chunk, vec_t (&d)[4][4], int part) {       // part 0: pixels 0..5, 1: 6..10, 2: 11..15
-        const int soff = chunk * CK * 4;
         const int lo = part == 0 ? 0 : part == 1 ? 6 : 11, hi = part == 0 ? 6 : part == 1 ? 11 : 16;
 #pragma unroll
-        for (int e = lo; e < hi; ++e) {
-            const int i = e >> 2, j = e & 3;
-            if constexpr (VEC == 2) {
-                d[i][j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xr, st_off[i][j], soff, 0));
-            } else {
-                d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, st_off[i][j], soff, 0));
-            }
-        }
+        for (int e = lo; e < hi; ++e) d[e >> 2][e & 3] = load_pixel(chunk, e >> 2, e & 3);
     };
     // transform in four pieces (one per k-step): piece 0 = B^T d, piece k = row k of (B^T d) B and its four LDS writes ... rows 0..3
     // are split 1 + 1 + 1 + 1 with the column transform in front of row 0
@@ -332,7 +357,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     // the tensor and the store is dropped by the bounds check; tiles are processed in register pairs (packed fp32 adds).
     const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
     const float lo = p.relu ? 0.f : -__builtin_inff();
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * Ho * Wo * Cout * 4), 0x00020000);
     const bool want_stats = p.stats != nullptr;
     int tinfo[16];
     unsigned tbase[16];
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) tbase[i] = ((unsigned)(tinfo[i] >> 3) * Cout + co) * 4u;
     float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
-    const unsigned row_b = (unsigned)W * Cout * 4, col_b = (unsigned)Cout * 4;
+    const unsigned row_b = (unsigned)Wo * Cout * 4, col_b = (unsigned)Cout * 4;
 #pragma unroll
     for (int ip = 0; ip < 8; ++ip) {
         const int i = 2 * ip;
@@ -371,7 +396,11 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
                 for (int c2 = 0; c2 < 2; ++c2) {
                     const float yv = y[a2][c2][e];
                     const unsigned off = v[a2][c2] ? base + a2 * row_b + c2 * col_b : 0xC0000000u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(yv + bv, lo)), yr, off, 0, 0);
+                    float z = fmaxf(yv + bv, lo);
+                    if constexpr (GEN != 0) {
+                        if (p.act == kActElu) z = yv + bv > 0.f ? yv + bv : expm1f(yv + bv);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, z), yr, off, 0, 0);
                 }
             if (want_stats) {
                 float ls = 0.f, lq = 0.f;
@@ -623,20 +652,25 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     }
 }
 
-template <int WT, int WC>
+template <int WT, int WC, int GEN = 0>
 void launch_wino(WinoParams& p, hipStream_t st) {
-    const int ntiles = p.B * ((p.H + 1) / 2) * ((p.W + 1) / 2);
+    const int Ho = GEN ? p.Ho : p.H, Wo = GEN ? p.Wo : p.W;
+    const int ntiles = p.B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
     p.tiles_x = (p.Cout + 32 * WC - 1) / (32 * WC);       // channel blocks
     p.tiles_y = (ntiles + 32 * WT - 1) / (32 * WT);       // tile blocks
     const size_t grid = (size_t)((p.tiles_y + 7) / 8) * 8 * p.tiles_x;
-    static const int dbg = getenv("DVS_WINO_DBG") ? atoi(getenv("DVS_WINO_DBG")) : 0;
+    if constexpr (GEN == 0) {
+        static const int dbg = getenv("DVS_WINO_DBG") ? atoi(getenv("DVS_WINO_DBG")) : 0;
 #define WINO_DBG_CASE(D) \
     case D: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, D>), dim3((unsigned)grid), dim3(NT), 0, st, p); break;
-    switch (dbg) {
-        WINO_DBG_CASE(1) WINO_DBG_CASE(2) WINO_DBG_CASE(4) WINO_DBG_CASE(8) WINO_DBG_CASE(15) WINO_DBG_CASE(16) WINO_DBG_CASE(31)
-        default: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC>), dim3((unsigned)grid), dim3(NT), 0, st, p);
-    }
+        switch (dbg) {
+            WINO_DBG_CASE(1) WINO_DBG_CASE(2) WINO_DBG_CASE(4) WINO_DBG_CASE(8) WINO_DBG_CASE(15) WINO_DBG_CASE(16) WINO_DBG_CASE(31)
+            default: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC>), dim3((unsigned)grid), dim3(NT), 0, st, p);
+        }
 #undef WINO_DBG_CASE
+    } else {
+        hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, GEN>), dim3((unsigned)grid), dim3(NT), 0, st, p);
+    }
 }
 
 }  // namespace
@@ -665,13 +699,42 @@ int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, floa
     DVS_REQUIRE(stat_groups >= 0 && stat_groups <= 2 && (stat_groups != 2 || (B & 1) == 0), "dvs_conv3x3_wino_fwd: stat_groups");
     DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
                 "dvs_conv3x3_wino_fwd: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    WinoParams p{x, u, bias, y, stats, B, H, W, Cin, Cout, 0, 0, relu, stat_groups == 2 ? B / 2 : 0x7fffffff};
+    WinoParams p{x, u, bias, y, stats, B, H, W, Cin, Cout, 0, 0, relu, stat_groups == 2 ? B / 2 : 0x7fffffff,
+                 nullptr, Cin, 0, 0, H, W, 1, relu ? kActRelu : 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
     prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
     if (Cout > 64) launch_wino<1, 4>(p, st);
     else launch_wino<2, 2>(p, st);
     return dvs::check_launch("dvs_conv3x3_wino_fwd");
+}
+
+int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const float* bias, float* y, int B, int H, int W, int C1, int C2,
+                         int Cout, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream) {
+    DVS_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && Cout > 0, "dvs_conv3x3_wino_gen: bad argument");
+    DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_wino_gen: x2 and C2 go together");
+    DVS_REQUIRE(C1 % 8 == 0 && (C1 + C2) % CIN_MULT == 0 && (Cout & 3) == 0,
+                "dvs_conv3x3_wino_gen: C1 %% 8 == 0, (C1 + C2) %% 16 == 0, Cout %% 4 == 0 (got %d, %d, %d)", C1, C2, Cout);
+    DVS_REQUIRE((org == 1 && Ho == H && Wo == W) || (org == 2 && Ho == H + 2 && Wo == W + 2 && !reflect),
+                "dvs_conv3x3_wino_gen: origin 1 = 'same' output, origin 2 = full correlation (H + 2, W + 2, zero padding)");
+    DVS_REQUIRE(!reflect || (H >= 2 && W >= 2), "dvs_conv3x3_wino_gen: ReflectionPad2d(1) needs H, W >= 2");
+    DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_wino_gen: upsampled input has even H, W");
+    DVS_REQUIRE(act == 0 || act == kActRelu || act == kActElu, "dvs_conv3x3_wino_gen: activation %d (0, 1 = ReLU, 2 = ELU)", act);
+    const int Cin = C1 + C2;
+    DVS_REQUIRE((double)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
+                "dvs_conv3x3_wino_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    WinoParams p{x, u, bias, y, nullptr, B, H, W, Cin, Cout, 0, 0, act == kActRelu, 0x7fffffff, x2, C1, upsample, reflect, Ho, Wo, org, act};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
+    prof.work(2.0 * B * (as_dgrad ? H * W : Ho * Wo) * Cout * (double)Cin * 9);
+    if (x2) {
+        if (Cout > 64) launch_wino<1, 4, 2>(p, st);
+        else launch_wino<2, 2, 2>(p, st);
+    } else {
+        if (Cout > 64) launch_wino<1, 4, 1>(p, st);
+        else launch_wino<2, 2, 1>(p, st);
+    }
+    return dvs::check_launch("dvs_conv3x3_wino_gen");
 }
 
 int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,

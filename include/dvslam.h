@@ -143,11 +143,19 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *   dvs_conv3x3_wino_fwd: y [B,H,W,Cout] = [relu](conv3x3(x [B,H,W,Cin]) + bias); stats (NULL = skip) [stat_groups][2][Cout] +=
  *                         per-channel sum / sum of squares of the raw output, as dvs_conv2d_fwd's epilogue does.  Cin % 16 == 0,
  *                         Cout % 4 == 0, tensors < 2 GiB.  as_dgrad: count the launch in the data-gradient profile slot.
+ *   dvs_conv3x3_wino_gen: the same kernel behind the decoder's gathers (model/layers.py:26-41 Conv3x3 = ReflectionPad2d(1) + 3x3,
+ *                         model/depth_decoder.py:52-62 upsample + concat): logical input [B,H,W,C1+C2] = cat(x [, x2]) where x is
+ *                         [B,H/2,W/2,C1] when `upsample` (nearest 2x in the gather) and x2 [B,H,W,C2] the skip (NULL / C2 = 0:
+ *                         none); reflect = 1: ReflectionPad2d(1), else zero padding; org = 1: y [B,H,W,Cout]; org = 2: the full
+ *                         correlation y [B,H+2,W+2,Cout] (the padded-domain data gradient that dvs_reflect_fold folds back);
+ *                         act: 0 none, 1 ReLU, 2 ELU.  C1 % 8 == 0, (C1+C2) % 16 == 0, Cout % 4 == 0.
  *   dvs_conv3x3_wino_wgrad: dw [Cout][3][3][Cin] += the weight gradient of that convolution from x [B,H,W,Cin] and dy [B,H,W,Cout]
  *                         (dL/dg = G^T [sum over tiles (A dY A^T) o (B^T d B)] G), the tile range split over about
  *                         target_workgroups (0 = default) workgroups that add into dw with float atomics (plain adds when
  *                         one workgroup owns a block).  Cin % 32 == 0, Cout % 32 == 0, tensors < 2 GiB. */
 int dvs_wino_weights(const float* w, float* u, int Cout, int Cin, int flip, void* stream);
+int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const float* bias, float* y, int B, int H, int W, int C1, int C2,
+                         int Cout, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream);
 int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
                            void* stream);
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);

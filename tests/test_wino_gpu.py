@@ -158,3 +158,65 @@ def test_rejects_what_it_does_not_cover():
     x, wt = _mk(1, 64, 64, 4, 4)
     with pytest.raises(_lib.DvsError):
         DC.conv3x3_wino(x[:, :32], wt)                 # channel mismatch
+
+
+DEC = [  # B, C1, C2 (skip channels; -1: no upsample, 0: upsample only), Cout, h, w of x
+    (2, 512, -1, 256, 15, 20), (2, 256, 256, 256, 15, 20), (2, 256, -1, 128, 30, 40), (2, 128, 128, 128, 30, 40),
+    (2, 128, -1, 64, 60, 80), (2, 64, 64, 64, 60, 80), (1, 64, 0, 64, 5, 7), (3, 72, 56, 80, 3, 2), (1, 64, -1, 64, 2, 2)]
+
+
+def _dec_ref(x, skip, up, wt, bias, act):
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if skip is not None:
+        xin = torch.cat([xin, skip], 1)
+    y = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), wt, bias)
+    return F.elu(y) if act == "elu" else y
+
+
+@pytest.mark.parametrize("B,c1,c2,co,h,w", DEC)
+def test_decoder_gather_forward_and_padded_data_gradient(B, c1, c2, co, h, w):
+    """ReflectionPad2d(1) + [upsample (+ concat)] + 3x3 + bias + ELU (model/layers.py:26-41, model/depth_decoder.py:52-62) and
+    the full correlation of the padded-domain data gradient, against fp64 torch."""
+    from deep_visual_slam_amd import conv as DC
+    g = torch.Generator(device="cuda").manual_seed(5)
+    up = c2 >= 0
+    H, W = (2 * h, 2 * w) if up else (h, w)
+    x = torch.randn(B, c1, h, w, device="cuda", generator=g).contiguous(memory_format=CL)
+    skip = torch.randn(B, c2, H, W, device="cuda", generator=g).contiguous(memory_format=CL) if c2 > 0 else None
+    ci = c1 + max(c2, 0)
+    wt = (torch.randn(co, ci, 3, 3, device="cuda", generator=g) * (2.0 / (ci * 9)) ** 0.5).contiguous(memory_format=CL)
+    bias = torch.randn(co, device="cuda", generator=g) * 0.1
+    x2 = skip if skip is not None else (DC.UPSAMPLE_ONLY if up else None)
+    for act in ("elu", None):
+        y = DC.conv3x3_wino_gen(x, x2, wt, bias, act, reflect=True)
+        ref = _dec_ref(x.double(), None if skip is None else skip.double(), up, wt.double(), bias.double(), act)
+        assert y.shape == ref.shape and _rel(y, ref) < TOL, act
+    dz = torch.randn(B, co, H, W, device="cuda", generator=g).contiguous(memory_format=CL)
+    gp = DC.conv3x3_wino_gen(dz, None, wt, reflect=False, full=True, flip=True)
+    ref = F.conv_transpose2d(dz.double(), wt.double())           # [B, ci, H+2, W+2]: gradient w.r.t. the padded input
+    assert gp.shape == ref.shape and _rel(gp, ref) < TOL
+
+
+@pytest.mark.parametrize("mode", ["plain", "skip", "up"])
+def test_decoder_layer_autograd_matches_torch(mode):
+    from deep_visual_slam_amd import conv as DC
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, c1, co, h, w = 2, 64, 64, 6, 8
+    up = mode != "plain"
+    c2 = 64 if mode == "skip" else 0
+    H, W = (2 * h, 2 * w) if up else (h, w)
+    x = torch.randn(B, c1, h, w, device="cuda", generator=g).contiguous(memory_format=CL).requires_grad_(True)
+    skip = torch.randn(B, c2, H, W, device="cuda", generator=g).contiguous(memory_format=CL).requires_grad_(True) if c2 else None
+    wt = (torch.randn(co, c1 + c2, 3, 3, device="cuda", generator=g) * 0.05).contiguous(memory_format=CL).requires_grad_(True)
+    bias = (torch.randn(co, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    assert DC.wino_dec_eligible(wt, 1, 1, True, "elu", x, skip if skip is not None else (DC.UPSAMPLE_ONLY if up else None), False, None)
+    y = DC.conv2d(x, wt, bias, 1, 0, reflect_pad=1, act="elu", x2=skip, upsample=up)
+    cot = torch.randn_like(y)
+    ins = [x, wt, bias] + ([skip] if skip is not None else [])
+    got = torch.autograd.grad(y, ins, cot)
+    d = [t.detach().double().requires_grad_(True) for t in ins]
+    ref = _dec_ref(d[0], d[3] if skip is not None else None, up, d[1], d[2], "elu")
+    want = torch.autograd.grad(ref, d, cot.double())
+    assert _rel(y, ref.detach()) < TOL
+    for a, b, tol in zip(got, want, (2e-5, 2e-5, 2e-5, 2e-5)):
+        assert _rel(a, b) < tol
