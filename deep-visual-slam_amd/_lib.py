@@ -83,6 +83,8 @@ _SIGNATURES = {
     "dvs_bn_bwd_workspace": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),
     "dvs_bn_bwd_apply": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "dvs_bn_bwd_reduce_ymask": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),
+    "dvs_bn_bwd_apply_ymask": (C.c_int, [_vp] * 9 + [C.c_size_t, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_last_error": (C.c_char_p, []),
     "dvs_set_deterministic": (C.c_int, [C.c_int]),
     "dvs_get_deterministic": (C.c_int, []),

@@ -4,10 +4,14 @@ The batch statistics arrive from the producing convolution's epilogue (`stats` =
 sum of squares), so nn.BatchNorm2d + add + ReLU of a torchvision BasicBlock tail is one HBM pass forward
 and two backward (model/resnet_encoder.py:100-111 through torchvision's BasicBlock).
 """
+import os
+
 import torch
 
 from . import _lib, gradsink, zeropool
 from ._lib import check, ptr
+
+_YMASK = os.environ.get("DVS_BN_YMASK", "1") != "0"     # ReLU mask of residual-free BatchNorms recomputed from y in the backward
 
 CL = torch.channels_last
 
@@ -61,7 +65,9 @@ class _BNAct(torch.autograd.Function):
                            z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_fwd")
         ctx.relu, ctx.groups = relu, groups
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
-        ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu else None)
+        # ReLU without a residual: the backward recomputes the mask from y (dvs_bn_bwd_*_ymask) and does not need z
+        ctx.ymask = bool(relu) and residual is None and _YMASK
+        ctx.save_for_backward(y, gamma, residual, res_gamma, fin, res_fin, z if relu and not ctx.ymask else None)
         return z
 
     @staticmethod
@@ -73,7 +79,7 @@ class _BNAct(torch.autograd.Function):
         M = B * H * W // G
         dz = dz if dz.is_contiguous(memory_format=CL) else dz.contiguous(memory_format=CL)
         st = _lib.stream()
-        need_du = ctx.relu or residual is not None
+        need_du = (ctx.relu or residual is not None) and not ctx.ymask
         du = torch.empty_like(y) if need_du else dz
         dy = torch.empty_like(y)
         pooled = gamma.is_leaf and gamma.grad is not None
@@ -92,12 +98,20 @@ class _BNAct(torch.autograd.Function):
             rsums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
             rgs, rbs = gradsink.target(rg_par), gradsink.target(rb_par)
             rsunk = rgs is not None and rbs is not None
-        check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(),
-                                  fin[0, 2].data_ptr(), fin[0, 3].data_ptr(), du.data_ptr() if need_du else None,
-                                  sums.data_ptr(), ptr(ws), M, C, G, st), "dvs_bn_bwd_reduce")
-        check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
-                                 ptr(gamma), sums.data_ptr(), dy.data_ptr(), M, C, ptr(gs) if sunk else None,
-                                 ptr(bs) if sunk else None, G, st), "dvs_bn_bwd_apply")
+        if ctx.ymask:
+            check(l.dvs_bn_bwd_reduce_ymask(dz.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
+                                            fin[0, 0].data_ptr(), fin[0, 1].data_ptr(), sums.data_ptr(), ptr(ws), M, C, G, st),
+                  "dvs_bn_bwd_reduce_ymask")
+            check(l.dvs_bn_bwd_apply_ymask(dz.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
+                                           fin[0, 0].data_ptr(), fin[0, 1].data_ptr(), ptr(gamma), sums.data_ptr(), dy.data_ptr(), M, C,
+                                           ptr(gs) if sunk else None, ptr(bs) if sunk else None, G, st), "dvs_bn_bwd_apply_ymask")
+        else:
+            check(l.dvs_bn_bwd_reduce(dz.data_ptr(), z.data_ptr() if ctx.relu else None, y.data_ptr(),
+                                      fin[0, 2].data_ptr(), fin[0, 3].data_ptr(), du.data_ptr() if need_du else None,
+                                      sums.data_ptr(), ptr(ws), M, C, G, st), "dvs_bn_bwd_reduce")
+            check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
+                                     ptr(gamma), sums.data_ptr(), dy.data_ptr(), M, C, ptr(gs) if sunk else None,
+                                     ptr(bs) if sunk else None, G, st), "dvs_bn_bwd_apply")
         if ds_res:
             check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[0, 2].data_ptr(),
                                       res_fin[0, 3].data_ptr(), None, rsums.data_ptr(), ptr(ws), M, C, G, st),

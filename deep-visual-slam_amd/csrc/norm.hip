@@ -185,12 +185,14 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
 // 4-channel vector); sums[0][c] += sum du, sums[1][c] += sum du * xhat; optionally writes du.
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, float* __restrict__ du_out,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ du_out,
                                                            float* __restrict__ sums, int M, int C, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
     {   // blockIdx.y = group: M rows each; the partial rows of group g follow those of group g - 1
         const size_t go = (size_t)blockIdx.y * M * C, po = (size_t)blockIdx.y * 4 * C;
         dz += go; y += go; mean += po; invstd += po;
+        if (scale) { scale += po; shift += po; }
         if (z) z += go;
         if (du_out) du_out += go;
         sums += (size_t)blockIdx.y * gridDim.x * 2 * C;
@@ -201,6 +203,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
     {
         const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        // ReLU mask recomputed from y (no residual): z = max(y * scale + shift, 0) in the forward kernel, the same expression here
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (scale) {
+            sc = *reinterpret_cast<const f32x4*>(scale + c);
+            sh = *reinterpret_cast<const f32x4*>(shift + c);
+        }
         constexpr int U = 4;                                            // rows in flight per lane
         for (int r = r0 + rl; r < r1; r += rlanes * U) {
             f32x4 g[U], zz[U], yy[U];
@@ -221,6 +229,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
                 if (z) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[u][j] = zz[u][j] > 0.f ? g[u][j] : 0.f;
+                } else if (scale) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[u][j] = yy[u][j] * sc[j] + sh[j] > 0.f ? g[u][j] : 0.f;
                 }
                 if (du_out) reinterpret_cast<f32x4*>(du_out)[o] = g[u];
 #pragma unroll
@@ -281,10 +292,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
                                                           float* __restrict__ dy, size_t n4, int C, float inv_count,
-                                                          float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+                                                          float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift) {
     {   // blockIdx.y = group
         const size_t go = (size_t)blockIdx.y * n4 * 4, po = (size_t)blockIdx.y * 4 * C;
         du += go; y += go; dy += go; mean += po; invstd += po;
+        if (scale) { scale += po; shift += po; }
         sums += (size_t)blockIdx.y * 2 * C;
     }
     if (blockIdx.x == 0 && dgamma_acc) {               // gradient sink: d gamma / d beta added straight into .grad
@@ -301,6 +314,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
         f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
         f32x4 ga = {1.f, 1.f, 1.f, 1.f};
         if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        if (scale) {                                    // `du` is dz: the ReLU mask is recomputed from y as in the reduction
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
+        }
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -380,8 +398,24 @@ size_t dvs_bn_bwd_workspace(size_t M, int C, int groups) {
     return (size_t)groups * blocks * 2 * C * sizeof(float);
 }
 
+static int dvs_bn_bwd_reduce_impl(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                                  const float* scale, const float* shift, float* du, float* sums, float* workspace, size_t M, int C,
+                                  int groups, void* stream);
+
 int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
                       float* du, float* sums, float* workspace, size_t M, int C, int groups, void* stream) {
+    return dvs_bn_bwd_reduce_impl(dz, z, y, mean, invstd, nullptr, nullptr, du, sums, workspace, M, C, groups, stream);
+}
+
+int dvs_bn_bwd_reduce_ymask(const float* dz, const float* y, const float* mean, const float* invstd, const float* scale,
+                            const float* shift, float* sums, float* workspace, size_t M, int C, int groups, void* stream) {
+    DVS_REQUIRE(scale && shift, "dvs_bn_bwd_reduce_ymask: scale / shift of the forward pass are required");
+    return dvs_bn_bwd_reduce_impl(dz, nullptr, y, mean, invstd, scale, shift, nullptr, sums, workspace, M, C, groups, stream);
+}
+
+static int dvs_bn_bwd_reduce_impl(const float* dz, const float* z, const float* y, const float* mean, const float* invstd,
+                                  const float* scale, const float* shift, float* du, float* sums, float* workspace, size_t M, int C,
+                                  int groups, void* stream) {
     DVS_REQUIRE(dz && y && mean && invstd && sums && workspace && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1,
                 "dvs_bn_bwd_reduce: bad argument");
     const int cv = C / 4;
@@ -393,7 +427,7 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
-                           invstd, du, workspace, (int)M, C, rpb);
+                           invstd, scale, shift, du, workspace, (int)M, C, rpb);
     }
     // one slice = one ordered sum per address (deterministic mode); 32 slices = 32 float atomics per address
     const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
@@ -402,16 +436,33 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
     return dvs::check_launch("dvs_bn_bwd_reduce");
 }
 
+static int dvs_bn_bwd_apply_impl(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                 const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
+                                 const float* scale, const float* shift, void* stream);
+
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
                      void* stream) {
+    return dvs_bn_bwd_apply_impl(du, y, mean, invstd, gamma, sums, dy, M, C, dgamma_acc, dbeta_acc, groups, nullptr, nullptr, stream);
+}
+
+int dvs_bn_bwd_apply_ymask(const float* dz, const float* y, const float* mean, const float* invstd, const float* scale,
+                           const float* shift, const float* gamma, const float* sums, float* dy, size_t M, int C, float* dgamma_acc,
+                           float* dbeta_acc, int groups, void* stream) {
+    DVS_REQUIRE(scale && shift, "dvs_bn_bwd_apply_ymask: scale / shift of the forward pass are required");
+    return dvs_bn_bwd_apply_impl(dz, y, mean, invstd, gamma, sums, dy, M, C, dgamma_acc, dbeta_acc, groups, scale, shift, stream);
+}
+
+static int dvs_bn_bwd_apply_impl(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
+                                 const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
+                                 const float* scale, const float* shift, void* stream) {
     DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1, "dvs_bn_bwd_apply: bad argument");
     DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_bwd_apply: gradient sinks come together");
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
-                       C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
+                       C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc, scale, shift);
     return dvs::check_launch("dvs_bn_bwd_apply");
 }
 

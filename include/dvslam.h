@@ -252,6 +252,14 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
                      void* stream);
+/* ReLU without a residual (bn1 of a BasicBlock, the stem): the mask z > 0 is recomputed from y with the forward's own
+ * expression max(y*scale + shift, 0) (scale / shift = rows 0 / 1 of dvs_bn_fwd's `fin` table), so the backward neither reads z
+ * nor writes / re-reads du: 5 tensor passes instead of 7.  `dz` takes du's place in the apply call. */
+int dvs_bn_bwd_reduce_ymask(const float* dz, const float* y, const float* mean, const float* invstd, const float* scale,
+                            const float* shift, float* sums, float* workspace, size_t M, int C, int groups, void* stream);
+int dvs_bn_bwd_apply_ymask(const float* dz, const float* y, const float* mean, const float* invstd, const float* scale,
+                           const float* shift, const float* gamma, const float* sums, float* dy, size_t M, int C, float* dgamma_acc,
+                           float* dbeta_acc, int groups, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a4  axis-angle + translation -> 4x4 camera motion

@@ -76,3 +76,34 @@ def test_maxpool_matches_torch_including_ties(gpu_device, shape):
     # a different tie rule would move whole gradient values between pixels
     assert torch.allclose(x1.grad, x2.grad, rtol=1e-6, atol=1e-6)
     assert torch.equal(x1.grad != 0, x2.grad != 0)
+
+
+def test_relu_mask_recomputed_from_y_equals_the_mask_from_z(gpu_device):
+    """Residual-free BatchNorm+ReLU (bn1 of a BasicBlock, the stem): the backward recomputes z > 0 as y*scale + shift > 0 with
+    the forward kernel's own expression (dvs_bn_bwd_*_ymask) -- every gradient must be identical, bit for bit, to the path
+    that reads the saved z, also with two statistics groups."""
+    import torch.nn as nn
+    from deep_visual_slam_amd import bn as DB
+    CL = torch.channels_last
+    torch.manual_seed(4)
+    for groups, (B, C, H, W) in ((1, (4, 64, 24, 40)), (2, (6, 128, 12, 20)), (1, (3, 512, 3, 5))):
+        y = torch.randn(B, C, H, W, device=gpu_device).contiguous(memory_format=CL)
+        cot = torch.randn_like(y)
+        gam, bet = torch.rand(C, device=gpu_device) + 0.5, torch.rand(C, device=gpu_device) * 0.6 - 0.3
+        out = []
+        for ymask in (True, False):
+            old, DB._YMASK = DB._YMASK, ymask
+            try:
+                m = nn.BatchNorm2d(C).to(gpu_device).train()
+                with torch.no_grad():
+                    m.weight.copy_(gam)
+                    m.bias.copy_(bet)
+                yy = y.clone().requires_grad_(True)
+                st = DB.channel_stats(yy.detach(), groups)
+                z = DB.bn_act(yy, m, st, relu=True, groups=groups)
+                z.backward(cot)
+                out.append((z.detach().clone(), yy.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone()))
+            finally:
+                DB._YMASK = old
+        for a, b in zip(*out):
+            assert torch.equal(a, b)
