@@ -62,7 +62,7 @@ _SIGNATURES = {
     "dvs_conv3x3_wino_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 13 + [_vp]),
     "dvs_conv3x3_wino_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
-    "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),
     "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv2d_pack_wt_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),

@@ -243,7 +243,7 @@ def _wino_weight(w, weight, flip):
     return ent[int(flip)]
 
 
-def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False):
+def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None):
     """y = conv3x3(x, weight) (stride 1, zero pad 1) on the Winograd kernel; flip: the data gradient of that convolution,
     x = dY [B,Cout,H,W] -> dX [B,Cin,H,W].  `weight` must be the parameter object itself (the operand cache is pinned to it)."""
     x, w = _nhwc(x), _nhwc(weight)
@@ -254,7 +254,12 @@ def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False):
         raise _lib.DvsError("conv3x3_wino: input has %d channels, the operand expects %d" % (cx, k))
     u = _wino_weight(w, weight, flip)
     y = torch.empty((B, n, H, W), device=x.device, dtype=torch.float32, memory_format=CL)
-    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0,
+    if residual is not None:
+        residual = _nhwc(residual)
+        if tuple(residual.shape) != tuple(y.shape):
+            raise _lib.DvsError("conv3x3_wino: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, residual.data_ptr() if residual is not None else None,
+                                          y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0,
                                           B, H, W, k, n, 0, int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
     return y
 
@@ -395,7 +400,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, x2, opts):
-        stride, pad, reflect, act, planar, scale, shift, want_stats = opts
+        stride, pad, reflect, act, planar, scale, shift, want_stats = opts[:8]
+        passthrough = len(opts) > 8 and opts[8]  # also return x itself: its gradient (a skip path's) meets the data gradient here
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
         groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
         stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
@@ -418,13 +424,24 @@ class _Conv2d(torch.autograd.Function):
         ctx.weight_ref = weight                  # the object the operand caches (_prepacked, _wino_packed) are pinned to
         ctx.up_only = x2 is UPSAMPLE_ONLY
         ctx.save_for_backward(x, weight, None if ctx.up_only else x2, y if ACT[act] else None)
+        ctx.passthrough = passthrough
+        if passthrough:
+            xa = x.view_as(x)
+            if want_stats:
+                ctx.mark_non_differentiable(stats)
+                return y, stats, xa
+            return y, xa
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy, _dstats=None):
+    def backward(ctx, dy, *more):
+        # extra output gradients: (d stats,) and / or (d x_alias,) in the order forward returned them
+        dxa = more[-1] if ctx.passthrough and more else None
+        if ctx.passthrough and dy is None:
+            return dxa, None, None, None, None
         x, weight, x2, y = ctx.saved_tensors     # (unpacking also runs autograd's in-place modification check)
         weight = ctx.weight_ref                  # same data; the parameter object itself for the cache lookups
         stride, pad, reflect, act, planar, scale, shift = ctx.opts
@@ -464,7 +481,8 @@ class _Conv2d(torch.autograd.Function):
             padded = (_PADDED and preact and reflect and stride == 1 and pad == 1 and weight.shape[2] == 3
                       and weight.shape[0] % 32 == 0 and ctx.x_shape[2] >= 2)
             if ctx.wino:
-                dx = conv3x3_wino(dy, weight, flip=True)
+                dx = conv3x3_wino(dy, weight, flip=True, residual=dxa)       # + the skip path's gradient in the epilogue
+                dxa = None
             elif x2 is None:
                 if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:
                     dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape, wino=ctx.wino_dec)
@@ -515,6 +533,8 @@ class _Conv2d(torch.autograd.Function):
                 for t in (x, dy, y, x2):
                     if isinstance(t, torch.Tensor):
                         t.record_stream(side)                # keep the allocator from recycling them under the kernel
+        if dxa is not None:
+            dx = dxa if dx is None else dx + dxa
         return dx, dw, db, dx2, None
 
 
@@ -590,7 +610,7 @@ def supported(x, weight, x2=None, planar=False, upsample=False):
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
-           planar_norm=None, want_stats=False):
+           planar_norm=None, want_stats=False, passthrough=False):
     """Differentiable fused convolution.  reflect_pad=1 means ReflectionPad2d(1) in front of a valid conv;
     x2 / upsample select the decoder's upsample(+concat) gather; planar_norm=(scale, shift) selects the
     encoder-conv1 path (planar image in, normalisation fused)."""
@@ -600,4 +620,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x
     if x2 is None and upsample:
         x2 = UPSAMPLE_ONLY
     # want_stats: also return [2][Cout] per-channel sum / sum of squares of y (BatchNorm batch statistics)
-    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift, int(want_stats)))
+    # passthrough: the result tuple ends with x itself as an output of the same autograd node -- a BasicBlock takes its identity
+    # branch from it, so that the skip gradient arrives in THIS node's backward and is added in the data-gradient kernel's
+    # epilogue instead of by a separate autograd accumulation pass
+    return _Conv2d.apply(x, weight, bias, x2, (stride, pad, reflect, act, planar, scale, shift, int(want_stats), bool(passthrough)))

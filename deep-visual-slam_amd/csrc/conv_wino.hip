@@ -42,6 +42,7 @@ struct WinoParams {
     int reflect;           // out-of-image patch pixels mirror (pad 1) instead of reading zero
     int Ho, Wo, org;       // output size and patch origin: output tile (2ty, 2tx) reads input rows 2ty - org ... (1: 'same', 2: full)
     int act;               // epilogue activation code of conv_common.h (0 none, 1 ReLU, 2 ELU)
+    const float* res;      // null, or a tensor of y's shape added to the convolution (before bias / activation)
 };
 
 // w [Cout][3][3][Cin] -> u [Cin][4][Cout][4] (flip = 0), or the data-gradient filter: u [Cout][4][Cin][4] from w rotated 180 degrees
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NT) void wino_weights_batch_kernel(const WinoEntry*
 // Three LDS buffers: the one written in chunk c was last read two barriers ago.
 // GEN: 0 = zero-padded 'same' convolution of one tensor (the BasicBlock layers); 1 = general gather from one source (reflection,
 // upsample, output size / origin); 2 = general gather from two concatenated sources.
-template <int WT, int WC, int DBG = 0, int GEN = 0>     // DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
+template <int WT, int WC, int DBG = 0, int GEN = 0, bool RES = false>     // RES: y += res (same shape); DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
 __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     static_assert(WT * WC == 4 && (WT == 1 || WT == 2), "four waves");
     constexpr int MT = 32 * WT, CK = 8, CKP = CK + 4, KH = 4, VEC = WT, PP = CK / VEC;
@@ -358,6 +359,8 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
     const float lo = p.relu ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * Ho * Wo * Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.res : p.y), 0,
+                                                                         RES ? (int)((size_t)p.B * Ho * Wo * Cout * 4) : 0, 0x00020000);
     const bool want_stats = p.stats != nullptr;
     int tinfo[16];
     unsigned tbase[16];
@@ -367,6 +370,16 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     for (int i = 0; i < 16; ++i) tbase[i] = ((unsigned)(tinfo[i] >> 3) * Cout + co) * 4u;
     float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
     const unsigned row_b = (unsigned)Wo * Cout * 4, col_b = (unsigned)Cout * 4;
+    float rv[RES ? 16 : 1][4];                            // residual values: all 64 loads in flight before the transform arithmetic
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned ob = ((tinfo[i] >= 0) & co_ok) ? tbase[i] : 0xC0000000u;      // (rows / columns past an odd edge: masked at the store)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                rv[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ob, (k >> 1) * row_b + (k & 1) * col_b, 0));
+        }
+    }
 #pragma unroll
     for (int ip = 0; ip < 8; ++ip) {
         const int i = 2 * ip;
@@ -394,8 +407,9 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
             for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
                 for (int c2 = 0; c2 < 2; ++c2) {
-                    const float yv = y[a2][c2][e];
+                    float yv = y[a2][c2][e];
                     const unsigned off = v[a2][c2] ? base + a2 * row_b + c2 * col_b : 0xC0000000u;
+                    if constexpr (RES) yv += rv[i + e][2 * a2 + c2];
                     float z = fmaxf(yv + bv, lo);
                     if constexpr (GEN != 0) {
                         if (p.act == kActElu) z = yv + bv > 0.f ? yv + bv : expm1f(yv + bv);
@@ -663,6 +677,10 @@ void launch_wino(WinoParams& p, hipStream_t st) {
         static const int dbg = getenv("DVS_WINO_DBG") ? atoi(getenv("DVS_WINO_DBG")) : 0;
 #define WINO_DBG_CASE(D) \
     case D: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, D>), dim3((unsigned)grid), dim3(NT), 0, st, p); break;
+        if (p.res) {
+            hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, 0, true>), dim3((unsigned)grid), dim3(NT), 0, st, p);
+            return;
+        }
         switch (dbg) {
             WINO_DBG_CASE(1) WINO_DBG_CASE(2) WINO_DBG_CASE(4) WINO_DBG_CASE(8) WINO_DBG_CASE(15) WINO_DBG_CASE(16) WINO_DBG_CASE(31)
             default: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC>), dim3((unsigned)grid), dim3(NT), 0, st, p);
@@ -692,15 +710,15 @@ int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroup
     return dvs::check_launch("dvs_wino_weights_batch");
 }
 
-int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* stats, int stat_groups, int B, int H,
-                         int W, int Cin, int Cout, int relu, int as_dgrad, void* stream) {
+int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
+                         int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream) {
     DVS_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_wino_fwd: bad argument");
     DVS_REQUIRE(Cin % CIN_MULT == 0 && (Cout & 3) == 0, "dvs_conv3x3_wino_fwd: Cin %% 16 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
     DVS_REQUIRE(stat_groups >= 0 && stat_groups <= 2 && (stat_groups != 2 || (B & 1) == 0), "dvs_conv3x3_wino_fwd: stat_groups");
     DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
                 "dvs_conv3x3_wino_fwd: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     WinoParams p{x, u, bias, y, stats, B, H, W, Cin, Cout, 0, 0, relu, stat_groups == 2 ? B / 2 : 0x7fffffff,
-                 nullptr, Cin, 0, 0, H, W, 1, relu ? kActRelu : 0};
+                 nullptr, Cin, 0, 0, H, W, 1, relu ? kActRelu : 0, res};
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
     prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
@@ -723,7 +741,7 @@ int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const 
     const int Cin = C1 + C2;
     DVS_REQUIRE((double)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
                 "dvs_conv3x3_wino_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    WinoParams p{x, u, bias, y, nullptr, B, H, W, Cin, Cout, 0, 0, act == kActRelu, 0x7fffffff, x2, C1, upsample, reflect, Ho, Wo, org, act};
+    WinoParams p{x, u, bias, y, nullptr, B, H, W, Cin, Cout, 0, 0, act == kActRelu, 0x7fffffff, x2, C1, upsample, reflect, Ho, Wo, org, act, nullptr};
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
     prof.work(2.0 * B * (as_dgrad ? H * W : Ho * Wo) * Cout * (double)Cin * 9);

@@ -5,6 +5,8 @@ kernels of libdvslam_hip.so.  There is no library (MIOpen / ATen) convolution, B
 the product: a shape the kernels do not cover raises `DvsError` instead of silently leaving the MI355X-native path
 (the A/B composition against PyTorch-ROCm's library ops lives in tools/miopen_compose.py, outside the package).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -113,6 +115,24 @@ def _eval_affine(bn):
     if bn.bias is not None:
         shift = shift + bn.bias
     return scale, shift
+
+
+_PASSTHROUGH = os.environ.get("DVS_SKIP_PASSTHROUGH", "1") != "0"
+
+
+def conv_bn_relu_with_identity(x, weight, bn, stride=1, padding=0):
+    """(relu(bn(conv(x))), x') for the first half of a BasicBlock without a downsample branch: x' is x, handed back as a second
+    output of the convolution's autograd node.  The block adds x' (not x) as its identity, so the skip path's gradient arrives in
+    that node's backward and is added in the data-gradient kernel's epilogue -- otherwise autograd sums the two gradients of x
+    with one more pass over the tensor (26 such passes, 0.64 ms, per VO step).  Outside the training path it is (conv_bn_act, x)."""
+    from . import bn as _bn
+    if not (_PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad and bn.training and not inference_mode(bn)
+            and not _lib.deterministic() and _conv.supported(x, weight, None, False) and _bn.supported_c(weight.shape[0], bn)):
+        return conv_bn_act(x, weight, bn, stride, padding, relu=True), x
+    _require_gpu(x, "conv_bn_act")
+    G = _batch_groups
+    y, st, xa = _conv.conv2d(x, weight, None, stride, padding, want_stats=G, passthrough=True)
+    return _bn.bn_act(y, bn, st, True, groups=G), xa
 
 
 def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None):

@@ -28,10 +28,12 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if self.downsample is None:
+            # identity taken from conv1's autograd node (nn_ops.conv_bn_relu_with_identity): one pass less in the backward
+            out, x = nn_ops.conv_bn_relu_with_identity(x, self.conv1.weight, self.bn1, self.stride, 1)
+            return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x)
         out = nn_ops.conv_bn_act(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
-        res = None
-        if self.downsample is not None:
-            res = (self.downsample[0].weight, self.downsample[1], self.stride)
+        res = (self.downsample[0].weight, self.downsample[1], self.stride)
         return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x, res=res)
 
 

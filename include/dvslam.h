@@ -140,7 +140,8 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *                         data gradient of the same convolution is dvs_conv3x3_wino_fwd(dy, u_flip) with Cin/Cout swapped).
  *   dvs_wino_weights_batch: both orientations of n weights in one launch; table rows {w, u, u_flip (pointers), Cout, Cin,
  *                         first workgroup, 0 (int32)} sorted by first workgroup, ceil(Cout*Cin/256) workgroups per entry.
- *   dvs_conv3x3_wino_fwd: y [B,H,W,Cout] = [relu](conv3x3(x [B,H,W,Cin]) + bias); stats (NULL = skip) [stat_groups][2][Cout] +=
+ *   dvs_conv3x3_wino_fwd: y [B,H,W,Cout] = [relu](conv3x3(x [B,H,W,Cin]) [+ res] + bias) (res: NULL or a tensor of y's shape -- the
+ *                         skip path's gradient when the call is a BasicBlock's conv1 data gradient); stats (NULL = skip) [stat_groups][2][Cout] +=
  *                         per-channel sum / sum of squares of the raw output, as dvs_conv2d_fwd's epilogue does.  Cin % 16 == 0,
  *                         Cout % 4 == 0, tensors < 2 GiB.  as_dgrad: count the launch in the data-gradient profile slot.
  *   dvs_conv3x3_wino_gen: the same kernel behind the decoder's gathers (model/layers.py:26-41 Conv3x3 = ReflectionPad2d(1) + 3x3,
@@ -159,8 +160,8 @@ int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const 
 int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
                            void* stream);
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
-int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, float* y, float* stats, int stat_groups, int B, int H,
-                         int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);
+int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
+                         int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
 /*   dvs_conv2d_pack_wt_batch: the same transpose for many weights in one launch.  `table` (device memory) = n_entries
  *   records { const float* w; float* wt; int Cout, Cin, taps, wg_begin; } (32 bytes each), wg_begin = number of

@@ -220,3 +220,34 @@ def test_decoder_layer_autograd_matches_torch(mode):
     assert _rel(y, ref.detach()) < TOL
     for a, b, tol in zip(got, want, (2e-5, 2e-5, 2e-5, 2e-5)):
         assert _rel(a, b) < tol
+
+
+@pytest.mark.parametrize("B,ci,co,h,w", [(2, 64, 64, 120, 160), (3, 128, 64, 13, 27), (2, 512, 512, 15, 20)])
+def test_residual_in_the_epilogue(B, ci, co, h, w):
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(B, ci, co, h, w, seed=7)
+    r = torch.randn(B, co, h, w, device="cuda").contiguous(memory_format=CL)
+    y = DC.conv3x3_wino(x, wt, residual=r)
+    assert _rel(y, F.conv2d(x.double(), wt.double(), None, 1, 1) + r.double()) < TOL
+
+
+def test_identity_passthrough_adds_the_skip_gradient_in_the_data_gradient():
+    """conv2d(..., passthrough=True) hands x back as an output of the same autograd node (nn_ops.conv_bn_relu_with_identity):
+    the gradient of everything that consumes that alias is added in the data-gradient epilogue, and the total must equal what
+    autograd computes for a tensor used twice."""
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(2, 64, 64, 12, 20, seed=8)
+    x.requires_grad_(True)
+    wt.requires_grad_(True)
+    y, st, xa = DC.conv2d(x, wt, None, 1, 1, want_stats=1, passthrough=True)
+    assert xa.data_ptr() == x.data_ptr() and not st.requires_grad
+    cot_y, cot_s = torch.randn_like(y), torch.randn_like(x)
+    ((y * cot_y).sum() + (torch.tanh(xa) * cot_s).sum()).backward()
+    x64, w64 = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    ((F.conv2d(x64, w64, None, 1, 1) * cot_y.double()).sum() + (torch.tanh(x64) * cot_s.double()).sum()).backward()
+    assert _rel(x.grad, x64.grad) < TOL and _rel(wt.grad, w64.grad) < 2e-5
+    # only the alias is used: the convolution's own branch gets no gradient
+    x2 = x.detach().clone().requires_grad_(True)
+    _, xa2 = DC.conv2d(x2, wt.detach(), None, 1, 1, passthrough=True)
+    (xa2 * cot_s).sum().backward()
+    assert torch.equal(x2.grad, cot_s)

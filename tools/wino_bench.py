@@ -34,7 +34,7 @@ def wino_fwd(x, u, cout, bias=None, relu=False, stats=None, groups=0, y=None):
     b, ci, h, w = x.shape
     if y is None:
         y = torch.empty((b, cout, h, w), device=x.device, memory_format=CL)
-    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), ptr(bias), y.data_ptr(), ptr(stats), groups, b, h, w, ci, cout,
+    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), ptr(bias), None, y.data_ptr(), ptr(stats), groups, b, h, w, ci, cout,
                                           int(relu), 0, _lib.stream()), "dvs_conv3x3_wino_fwd")
     return y
 
@@ -80,7 +80,7 @@ if os.environ.get("WINO_SWEEP"):
         y = torch.empty((B, 128, 60, 80), device=dev).contiguous(memory_format=CL)
         l = _lib.lib(); st = _lib.stream()
         def go():
-            l.dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, y.data_ptr(), None, 0, B, 60, 80, ci, 128, 0, 0, st)
+            l.dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), None, 0, B, 60, 80, ci, 128, 0, 0, st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5): go()
         e0.record()
