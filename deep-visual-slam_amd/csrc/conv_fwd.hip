@@ -555,8 +555,13 @@ void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
         // (statistics epilogue): layers 3 / 4 of a batch-4 step
         static const bool small_m = [] { const char* e = getenv("DVS_CONV_SMALLM"); return !(e && e[0] == '0'); }();
         const int t64 = ((M + 63) / 64) * ((s.Cout + 127) / 128);
+        // 128 x 128 tiles run two workgroups per CU (512 at a time): when the last of at most three rounds is mostly empty (the ViT
+        // token GEMMs: 1 032 tiles = 2.02 rounds -> 3), 64-row tiles waste half as much (fc1 62 -> 92 TF, qkv 72 -> 92 TF)
+        const int t128 = ((M + 127) / 128) * ((s.Cout + 127) / 128);
+        const double rounds = t128 / 512.0, full = ceil(rounds);
+        const bool tail_waste = rounds <= 3.2 && (full - rounds) / full > 0.2;
         if (small_m && MODE != IN_DGRAD && p.stats && t64 < 160) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
-        else if (small || ((M + 127) / 128) * ((s.Cout + 127) / 128) < 448) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
+        else if (small || t128 < 448 || tail_waste) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
         else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, slot);
     } else if (s.Cout > 32) {
         if (small) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
