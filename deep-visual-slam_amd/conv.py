@@ -206,6 +206,7 @@ def _packed_weight(w, weight):
 
 # ---- Winograd F(2x2, 3x3) path of the stride-1 3x3 BasicBlock convolutions (csrc/conv_wino.hip) ------------------------
 _WINO = os.environ.get("DVS_WINOGRAD", "1") != "0"
+_WINO_FORCE = os.environ.get("DVS_WINOGRAD", "1") == "force"       # take the Winograd kernels whatever the cost model says (tests)
 _wino_packed = {}   # weight.data_ptr() -> [u, u_flip, weight._version, shape, weakref]  (either operand may be None)
 
 
@@ -216,6 +217,20 @@ def wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale):
     co, ci, kh, kw = weight.shape
     return (_WINO and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not reflect and act is None and x2 is None
             and not planar and scale is None and ci % 16 == 0 and co % 16 == 0 and ci >= 64 and co >= 64)
+
+
+def wino_pays(B, H, W, k, n):
+    """Cost model for ONE launch (microseconds; fitted to tools/wino_bench.py at batch 2 ... 24): the Winograd kernel runs one
+    workgroup per CU whose duration is set by the reduction length alone, so it only wins when there are enough tiles --
+    layer 4 at batch 2 has 20 workgroups of 132 us against 42 us for the direct kernel with its small tiles and split K."""
+    if _WINO_FORCE:
+        return True
+    tiles = B * ((H + 1) // 2) * ((W + 1) // 2)
+    mt, nc = (64, 64) if n <= 64 else (32, 128)
+    wgs = -(-tiles // mt) * -(-n // nc)
+    t_wino = -(-wgs // 256) * (7.0 + 0.245 * k)
+    t_direct = 25.0 + 2.0 * B * H * W * n * k * 9 / 120e6
+    return t_wino < 0.9 * t_direct
 
 
 def _wino_alloc(weight):
@@ -406,10 +421,13 @@ class _Conv2d(torch.autograd.Function):
         groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
         stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
         ctx.wino = (bias is None and wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale) and x.shape[1] == weight.shape[1]
-                    and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)      # 32-bit buffer offsets
+                    and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31      # 32-bit buffer offsets
+                    and wino_pays(x.shape[0], x.shape[2], x.shape[3], weight.shape[1], weight.shape[0]))
+        up2 = 2 if x2 is not None else 1
         ctx.wino_dec = (not ctx.wino and not groups and wino_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale)
-                        and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * (4 if x2 is not None else 1)
-                        * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
+                        and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2
+                        * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
+                        and wino_pays(x.shape[0], up2 * x.shape[2], up2 * x.shape[3], weight.shape[1], weight.shape[0]))
         if ctx.wino:
             y = conv3x3_wino(x, weight, stats, groups)
         elif ctx.wino_dec:

@@ -560,7 +560,9 @@ void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
         const int t128 = ((M + 127) / 128) * ((s.Cout + 127) / 128);
         const double rounds = t128 / 512.0, full = ceil(rounds);
         const bool tail_waste = rounds <= 3.2 && (full - rounds) / full > 0.2;
-        if (small_m && MODE != IN_DGRAD && p.stats && t64 < 160) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
+        // ... and for plain 1x1 products (token GEMMs of a single ViT frame: 1 370 rows) that leave CUs without a 64 x 128 tile
+        const bool gemm_small = s.kh == 1 && s.kw == 1 && MODE != IN_DGRAD && t64 < 224;
+        if (small_m && MODE != IN_DGRAD && ((p.stats && t64 < 160) || gemm_small)) launch_cfg<64, 64, 2, 2, MODE, FOLD>(p, st, slot);
         else if (small || t128 < 448 || tail_waste) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, slot);
         else launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, slot);
     } else if (s.Cout > 32) {

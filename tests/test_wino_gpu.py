@@ -7,6 +7,26 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 CL = torch.channels_last
+
+
+@pytest.fixture(autouse=True)
+def _always_winograd():
+    """The product picks the Winograd kernels by a cost model (conv.wino_pays: enough tiles to fill the chip); these tests
+    exercise the kernels at every size."""
+    from deep_visual_slam_amd import conv as DC
+    old, DC._WINO_FORCE = DC._WINO_FORCE, True
+    yield
+    DC._WINO_FORCE = old
+
+
+def test_cost_model_keeps_small_problems_on_the_direct_kernels():
+    from deep_visual_slam_amd import conv as DC
+    DC._WINO_FORCE = False
+    # layer 1 .. 4 of the encoder at 480x640 (input of the 3x3 layers): batch 12 and 24 all Winograd, batch 1 only layer 1
+    shapes = [(64, 120, 160), (128, 60, 80), (256, 30, 40), (512, 15, 20)]
+    assert all(DC.wino_pays(12, h, w, c, c) and DC.wino_pays(24, h, w, c, c) for c, h, w in shapes)
+    assert [DC.wino_pays(1, h, w, c, c) for c, h, w in shapes] == [True, False, False, False]
+    assert not DC.wino_pays(2, 15, 20, 512, 512)          # 20 workgroups of 132 us against 42 us (tools/wino_bench.py, batch 2)
 TOL = 3e-6        # max |err| / max |ref|; the direct kernel and MIOpen sit at 1-4e-6 on the same shapes (tools/wino_bench.py)
 
 
@@ -131,7 +151,7 @@ def test_autograd_path_selects_it_and_matches_torch():
     x, wt = _mk(4, 64, 128, 24, 32)
     x.requires_grad_(True)
     wt.requires_grad_(True)
-    assert DC.wino_eligible(wt, 1, 1, False, None, None, False, None)
+    assert DC.wino_eligible(wt, 1, 1, False, None, None, False, None) and DC.wino_pays(4, 24, 32, 64, 128)
     y, st = DC.conv2d(x, wt, None, 1, 1, want_stats=1)
     gy = torch.randn_like(y)
     y.backward(gy)
