@@ -190,6 +190,21 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         int bb, ty, tx;
         tile_coords(min(t, ntiles - 1), bb, ty, tx);
         const int iy0 = 2 * ty - org, ix0 = 2 * tx - org;
+        if constexpr (GEN == 0) {
+            // one multiply chain for the patch origin, the 16 pixels by adding wave-uniform strides; a pixel outside the image
+            // (or a tile past the end) gets the out-of-bounds mask OR-ed in (every tensor is smaller than 2 GiB)
+            const unsigned base = (unsigned)((((bb * H + iy0) * W + ix0) * Cin + VEC * st_c) * 4);
+            const unsigned dead = t < ntiles ? 0u : 0xC0000000u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned rm = (unsigned)(iy0 + i) < (unsigned)H ? dead : 0xC0000000u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned cm = (unsigned)(ix0 + j) < (unsigned)W ? 0u : 0xC0000000u;
+                    st_off[i][j] = (base + (unsigned)((i * W + j) * Cin * 4)) | rm | cm;
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -207,6 +222,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
                 st_off[i][j] = ok ? (unsigned)((((bb * Hs + sy) * Ws + sx) * C1 + VEC * st_c) * 4) : 0xC0000000u;
                 if constexpr (GEN == 2) st_off2[i][j] = ok ? (unsigned)((((bb * H + iy) * W + ix) * C2 + VEC * st_c) * 4) : 0xC0000000u;
             }
+        }
     }
     using vec_t = typename std::conditional<VEC == 2, f32x2, float>::type;
     auto load_pixel = [&](int chunk, int i, int j) -> vec_t {
@@ -269,12 +285,6 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     };
     load_u(0, 0);
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
-
     const int nchunk = Cin / CK;
     vec_t stg[4][4], tt[4][4];
     f32x4 a[16], an[16];
@@ -296,6 +306,11 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     }
     __syncthreads();
     read_a(0, a);
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
     // one chunk: MFMAs of chunk ch from `ac`; `anx` <- A operands of chunk ch + 1.  Every k-step is one scheduling region in which
     // the next k-step's B operands, a quarter of the A reads, a transform piece and a third of the stage loads are interleaved
@@ -339,10 +354,12 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         bnext = bwrite;
         bwrite = bfree;
     };
-    for (int ch = 0; ch < nchunk; ch += 2) {               // Cin % 16 == 0: an even number of chunks
-        chunk_body(ch, a, an);
+    int ch = 0;
+    do {                                                   // Cin % 16 == 0: an even, non-zero number of chunks (no loop guard:
+        chunk_body(ch, a, an);                             // with one the compiler zeroes the 256 accumulators on both paths)
         chunk_body(ch + 1, an, a);
-    }
+        ch += 2;
+    } while (ch < nchunk);
 
     // ---- output transform, bias / ReLU / statistics, store: reg i <-> tile m = (i & 3) + 8 (i >> 2) + 4 h of my channel
     if (DBG & 16) {
