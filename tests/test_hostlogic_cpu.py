@@ -220,3 +220,26 @@ def test_color_jitter_oracle_identity_and_range():
     assert float((same - img).abs().max()) < 1e-5
     out = OI.color_jitter(img, [3, 1, 0, 2], [1.3, 0.7, 1.3, -0.2])
     assert float(out.min()) >= 0.0 and float(out.max()) <= 1.0 and float((out - img).abs().max()) > 0.05
+
+
+def test_winograd_cost_model_and_eligibility():
+    """conv.wino_pays / wino_eligible / wino_dec_eligible are host logic: which launches take the Winograd kernels."""
+    import torch
+    from deep_visual_slam_amd import conv as DC
+    enc = [(64, 120, 160), (128, 60, 80), (256, 30, 40), (512, 15, 20)]          # stride-1 3x3 layers of ResNet-18 at 480x640
+    assert all(DC.wino_pays(12, h, w, c, c) and DC.wino_pays(24, h, w, c, c) for c, h, w in enc)
+    assert [DC.wino_pays(1, h, w, c, c) for c, h, w in enc] == [True, False, False, False]
+    assert [DC.wino_pays(4, h, w, c, c) for c, h, w in enc] == [True, True, False, False]
+    w = torch.empty(128, 64, 3, 3)
+    assert DC.wino_eligible(w, 1, 1, False, None, None, False, None)
+    assert not DC.wino_eligible(w, 2, 1, False, None, None, False, None)          # stride 2
+    assert not DC.wino_eligible(w, 1, 1, True, None, None, False, None)           # reflection pad: the decoder's variant
+    assert not DC.wino_eligible(w, 1, 1, False, "relu", None, False, None)        # fused activation
+    assert not DC.wino_eligible(torch.empty(128, 48, 3, 3), 1, 1, False, None, None, False, None)      # K % 16, K >= 64
+    assert not DC.wino_eligible(torch.empty(128, 64, 1, 1), 1, 0, False, None, None, False, None)
+    x, skip = torch.empty(2, 64, 6, 8), torch.empty(2, 64, 12, 16)
+    wd = torch.empty(64, 128, 3, 3)
+    assert DC.wino_dec_eligible(wd, 1, 1, True, "elu", x, skip, False, None)
+    assert not DC.wino_dec_eligible(wd, 1, 1, True, "elu", x, torch.empty(2, 32, 12, 16), False, None)     # channels do not add up
+    assert not DC.wino_dec_eligible(wd, 1, 1, True, "sigmoid", x, skip, False, None)
+    assert DC.wino_wgrad_eligible((128, 64, 3, 3)) and not DC.wino_wgrad_eligible((48, 64, 3, 3))
