@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
 MAX_SCALES = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = C.c_void_p
 
@@ -69,13 +69,18 @@ _SIGNATURES = {
     "dvs_reflect_fold": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_act_bwd": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_int, _vp]),
     "dvs_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp, C.c_int, _vp]),
+    "dvs_conv2d_dgrad_res": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "dvs_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp, C.c_int, _vp]),
     "dvs_conv2d_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.c_int, _vp]),
     "dvs_conv2d_head_bwd": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp]),
+    "dvs_conv2d_head_bwd_res": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp, _vp]),
     "dvs_maxpool3x3s2_fwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_maxpool3x3s2_bwd": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_maxpool3x3s2_bwd_res": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_upsample2x_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_upsample2x_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_bn_relu_maxpool_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_bn_relu_maxpool_bwd": (C.c_int, [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_bn_fwd": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),

@@ -128,6 +128,74 @@ class _BNAct(torch.autograd.Function):
         return dy, d_gamma, d_beta, d_res, d_rg, d_rb, None, None, None, None
 
 
+class _BNReluPool(torch.autograd.Function):
+    """(maxpool3x3s2(z) [, z]) with z = relu(bn(y)) -- the stem tail of model/resnet_encoder.py:102-104 (bn1, relu, maxpool) in
+    one forward pass over y (dvs_bn_relu_maxpool_fwd; z is only written when a caller reads it: DepthNet's finest skip) and two
+    backward passes (dvs_bn_relu_maxpool_bwd) that gather the pool gradient instead of reading a materialised dz."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, fin, groups, need_z):
+        B, C, H, W = y.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        pooled = torch.empty((B, C, Ho, Wo), device=y.device, dtype=torch.float32, memory_format=CL)
+        idx = torch.empty((B, Ho, Wo, C), device=y.device, dtype=torch.uint8)
+        z = torch.empty_like(y) if need_z else None
+        check(_lib.lib().dvs_bn_relu_maxpool_fwd(y.data_ptr(), fin.data_ptr(), z.data_ptr() if need_z else None, pooled.data_ptr(), idx.data_ptr(), B, H, W, C,
+                                                 groups, _lib.stream()), "dvs_bn_relu_maxpool_fwd")
+        ctx.groups = groups
+        ctx.affine = (gamma, beta)               # only to find their gradient sinks in backward
+        ctx.save_for_backward(y, gamma, fin, idx)
+        ctx.set_materialize_grads(False)
+        return (pooled, z) if need_z else pooled
+
+    @staticmethod
+    def backward(ctx, dpool, dz=None):
+        if dpool is None and dz is None:
+            return None, None, None, None, None, None
+        y, gamma, fin, idx = ctx.saved_tensors
+        l = _lib.lib()
+        G = ctx.groups
+        B, C, H, W = y.shape
+        M = (B // G) * H * W
+        if dpool is None:
+            dpool = zeropool.zeros((B, idx.shape[1], idx.shape[2], C), y.device).permute(0, 3, 1, 2)
+        dpool = dpool if dpool.is_contiguous(memory_format=CL) else dpool.contiguous(memory_format=CL)
+        if dz is not None:
+            dz = dz if dz.is_contiguous(memory_format=CL) else dz.contiguous(memory_format=CL)
+        dy = torch.empty_like(y)
+        pooled = gamma.is_leaf and gamma.grad is not None
+        sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
+        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
+        g_par, b_par = ctx.affine
+        gs, bs = gradsink.target(g_par), gradsink.target(b_par)
+        sunk = gs is not None and bs is not None
+        for par in ctx.affine:
+            gradsink.note(par, torch.cuda.current_stream())
+        check(l.dvs_bn_relu_maxpool_bwd(dpool.data_ptr(), idx.data_ptr(), dz.data_ptr() if dz is not None else None, y.data_ptr(), fin.data_ptr(), ptr(gamma),
+                                        sums.data_ptr(), ptr(ws), dy.data_ptr(), B, H, W, C, ptr(gs) if sunk else None,
+                                        ptr(bs) if sunk else None, G, _lib.stream()), "dvs_bn_relu_maxpool_bwd")
+        d_gamma = d_beta = None
+        if not sunk:
+            d_gamma, d_beta = (sums[0, 1], sums[0, 0]) if G == 1 else (sums[:, 1].sum(0), sums[:, 0].sum(0))
+        return dy, d_gamma, d_beta, None, None, None
+
+
+def bn_relu_pool(y, bn, stats, groups=1, need_z=True):
+    """(z or None, maxpool3x3s2(z)) with z = relu(bn(y)), training-mode BatchNorm with the batch statistics in `stats` (from the
+    conv epilogue), running statistics updated as bn_act does."""
+    if not y.is_cuda:
+        raise _lib.DvsError("bn_relu_pool: GPU tensors only; this package has no CPU path")
+    B, C, H, W = y.shape
+    if B % groups:
+        raise _lib.DvsError("bn_relu_pool: batch %d does not split into %d groups" % (B, groups))
+    count = (B // groups) * H * W
+    y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
+    st = stats if stats.dim() == 3 else stats.unsqueeze(0)
+    fin = _finalize_groups(st, count, bn, groups)
+    out = _BNReluPool.apply(y, bn.weight, bn.bias, fin, groups, bool(need_z))
+    return (out[1], out[0]) if need_z else (None, out)
+
+
 def channel_stats(y, groups=1):
     """[G][2][C] per-channel sum / sum of squares of y (NHWC) in a fixed summation order: the deterministic stand-in for the
     convolution's atomic statistics epilogue (dvs_set_deterministic).  It is the BatchNorm backward's reduction kernel with

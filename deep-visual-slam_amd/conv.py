@@ -258,9 +258,9 @@ def _wino_weight(w, weight, flip):
     return ent[int(flip)]
 
 
-def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None):
-    """y = conv3x3(x, weight) (stride 1, zero pad 1) on the Winograd kernel; flip: the data gradient of that convolution,
-    x = dY [B,Cout,H,W] -> dX [B,Cin,H,W].  `weight` must be the parameter object itself (the operand cache is pinned to it)."""
+def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None, bias=None, relu=False):
+    """y = [relu](conv3x3(x, weight) [+ bias]) (stride 1, zero pad 1) on the Winograd kernel; flip: the data gradient of that
+    convolution, x = dY [B,Cout,H,W] -> dX [B,Cin,H,W].  `weight` must be the parameter object itself (the operand cache is pinned to it)."""
     x, w = _nhwc(x), _nhwc(weight)
     co, ci = weight.shape[:2]
     k, n = (co, ci) if flip else (ci, co)
@@ -273,9 +273,9 @@ def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None
         residual = _nhwc(residual)
         if tuple(residual.shape) != tuple(y.shape):
             raise _lib.DvsError("conv3x3_wino: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), None, residual.data_ptr() if residual is not None else None,
+    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), ptr(bias), residual.data_ptr() if residual is not None else None,
                                           y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0,
-                                          B, H, W, k, n, 0, int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
+                                          B, H, W, k, n, int(bool(relu)), int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
     return y
 
 
@@ -345,10 +345,11 @@ def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
     return None if dw_out is not None else dw
 
 
-def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False):
+def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False, residual=None):
     """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
     split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
-    (d coarse [B,C1,H/2,W/2] -- the 2x2-summed gradient of the upsampled operand, d skip [B,Cin-C1,H,W] or None)."""
+    (d coarse [B,C1,H/2,W/2] -- the 2x2-summed gradient of the upsampled operand, d skip [B,Cin-C1,H,W] or None).
+    residual [B,Cin,H,W]: another gradient of the same input (a skip / downsample path's), added in the kernel's epilogue."""
     l = _lib.lib()
     dy = _nhwc(dy)
     w = _nhwc(weight)
@@ -361,6 +362,8 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
     if split_c1:
+        if residual is not None:
+            raise _lib.DvsError("conv2d_dgrad: a residual cannot be combined with the upsample+concat split")
         dx = zeropool.zeros((B, H // 2, W // 2, split_c1), dy.device).permute(0, 3, 1, 2)      # NHWC memory
         dskip = (torch.empty((B, Cin - split_c1, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
                  if split_c1 < Cin else None)
@@ -369,8 +372,12 @@ def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None
               "dvs_conv2d_dgrad")
         return dx, dskip
     dx = torch.empty((B, Cin, H, W), device=dy.device, dtype=torch.float32, memory_format=CL)
-    check(l.dvs_conv2d_dgrad(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact, None, 0, _lib.stream()),
-          "dvs_conv2d_dgrad")
+    if residual is not None:
+        residual = _nhwc(residual)
+        if tuple(residual.shape) != tuple(dx.shape):
+            raise _lib.DvsError("conv2d_dgrad: residual shape %s != gradient shape %s" % (tuple(residual.shape), tuple(dx.shape)))
+    check(l.dvs_conv2d_dgrad_res(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), C.byref(d), yo, dact, None, 0,
+                                 residual.data_ptr() if residual is not None else None, _lib.stream()), "dvs_conv2d_dgrad")
     return dx
 
 
@@ -420,7 +427,10 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
         groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
         stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
-        ctx.wino = (bias is None and wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale) and x.shape[1] == weight.shape[1]
+        # bias + ReLU (PoseNet's decoder, model/posenet_single.py:160-164) ride in the Winograd epilogue; the backward then forms
+        # dZ = dY * [Y > 0] and the bias gradient in one pre-activation pass (dvs_act_bwd), which needs Cout / 4 to divide 256
+        wino_tail = (bias is None and act is None) or (act == "relu" and not groups and 256 % max(weight.shape[0] // 4, 1) == 0)
+        ctx.wino = (wino_tail and wino_eligible(weight, stride, pad, reflect, None, x2, planar, scale) and x.shape[1] == weight.shape[1]
                     and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31      # 32-bit buffer offsets
                     and wino_pays(x.shape[0], x.shape[2], x.shape[3], weight.shape[1], weight.shape[0]))
         up2 = 2 if x2 is not None else 1
@@ -429,7 +439,7 @@ class _Conv2d(torch.autograd.Function):
                         * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
                         and wino_pays(x.shape[0], up2 * x.shape[2], up2 * x.shape[3], weight.shape[1], weight.shape[0]))
         if ctx.wino:
-            y = conv3x3_wino(x, weight, stats, groups)
+            y = conv3x3_wino(x, weight, stats, groups, bias=bias, relu=act == "relu")
         elif ctx.wino_dec:
             y = conv3x3_wino_gen(x, x2, weight, bias, act, reflect=True)
         else:
@@ -470,8 +480,8 @@ class _Conv2d(torch.autograd.Function):
             x2 = UPSAMPLE_ONLY
         preact = False
         pre_db = None        # bias gradient already taken by the pre-activation pass (tensor to hand back, or True if sunk)
-        if (_PREACT and ACT[act] and reflect and not planar and weight.shape[0] >= 64 and (ctx.needs_input_grad[0] or x2 is not None)
-                and ctx.needs_input_grad[1]):
+        if ACT[act] and (ctx.wino or (_PREACT and reflect and not planar and weight.shape[0] >= 64
+                                      and (ctx.needs_input_grad[0] or x2 is not None) and ctx.needs_input_grad[1])):
             # wide decoder layers: form dZ = dY * act'(Y) once instead of in both gradient kernels' gathers (the data
             # gradient re-derives it for every tap and N tile), and take the bias gradient (column sums of dZ) in the same
             # pass -- the weight gradient then has neither an activation nor a bias path and runs on the LDS-DMA kernel
@@ -505,7 +515,8 @@ class _Conv2d(torch.autograd.Function):
                 if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:
                     dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape, wino=ctx.wino_dec)
                 else:
-                    dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act)
+                    dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act, residual=dxa)   # + the other paths' gradient
+                    dxa = None
             else:
                 C1, H, W = ctx.x_shape[1], 2 * ctx.x_shape[2], 2 * ctx.x_shape[3]
                 # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split: both done in
@@ -561,7 +572,8 @@ class _HeadConv(torch.autograd.Function):
     and PoseNet's last 1x1 (dvs_conv2d_head_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, reflect, act):
+    def forward(ctx, x, weight, bias, pad, reflect, act, passthrough=False):
+        x_in = x
         x, w = _nhwc(x), _nhwc(weight)
         B, Cin, H, W = x.shape
         d = _desc(B, Cin, H, W, weight.shape, 1, pad, reflect)
@@ -572,10 +584,18 @@ class _HeadConv(torch.autograd.Function):
         ctx.pooled = _has_grad(weight) and (bias is None or _has_grad(bias))
         ctx.params = (weight, bias)              # only to find their gradient sinks in backward
         ctx.save_for_backward(x, w, y)
+        ctx.passthrough = passthrough
+        if passthrough:
+            # x handed on as a second output (the decoder's next level reads it): its gradient comes back into THIS node and is
+            # added in the data-gradient kernel instead of by an autograd accumulation pass
+            ctx.set_materialize_grads(False)
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxa=None):
+        if dy is None:                           # (passthrough only) the head's own output was not used
+            return dxa, None, None, None, None, None, None
         gradsink.wait_pending(dy)                # a disparity gradient may still be on its way on another stream
         x, w, y = ctx.saved_tensors
         pad, reflect, act, has_bias = ctx.cfg
@@ -590,14 +610,18 @@ class _HeadConv(torch.autograd.Function):
         gradsink.note(ctx.params[1], torch.cuda.current_stream())
         dw = wsink if wsink is not None else zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
         db = bsink if bsink is not None else (zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None)
-        check(_lib.lib().dvs_conv2d_head_bwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(),
-                                             dx.data_ptr() if dx is not None else None, dw.data_ptr(), ptr(db), C.byref(d),
-                                             ACT[act], _lib.stream()), "dvs_conv2d_head_bwd")
+        res = None
+        if dxa is not None and dx is not None:
+            res = _nhwc(dxa)
+        check(_lib.lib().dvs_conv2d_head_bwd_res(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(),
+                                                 dx.data_ptr() if dx is not None else None, dw.data_ptr(), ptr(db), C.byref(d),
+                                                 ACT[act], res.data_ptr() if res is not None else None, _lib.stream()),
+              "dvs_conv2d_head_bwd")
         if wsink is not None:
             dw = None
         if bsink is not None:
             db = None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def head_supported(x, weight, stride, padding, reflect_pad, x2=None, upsample=False, planar=False):
@@ -607,9 +631,10 @@ def head_supported(x, weight, stride, padding, reflect_pad, x2=None, upsample=Fa
             and not upsample and not planar and cout * kh * kw * cin * 4 <= 60 * 1024)
 
 
-def head_conv2d(x, weight, bias, padding, reflect_pad, act):
+def head_conv2d(x, weight, bias, padding, reflect_pad, act, passthrough=False):
+    """passthrough: returns (y, x') with x' = x as a second output of the same autograd node (see _HeadConv.forward)."""
     pad, reflect = (reflect_pad, True) if reflect_pad else (padding, False)
-    return _HeadConv.apply(x, weight, bias, pad, reflect, act)
+    return _HeadConv.apply(x, weight, bias, pad, reflect, act, bool(passthrough))
 
 
 def supported(x, weight, x2=None, planar=False, upsample=False):

@@ -48,7 +48,7 @@ enum ProfSlot { SLOT_CHAIN_FWD = 0, SLOT_CHAIN_BWD, SLOT_ADAM, SLOT_CONV_FWD, SL
                 SLOT_BN_FWD, SLOT_BN_BWD, SLOT_ATTN, SLOT_ATTN_BWD, SLOT_COUNT };
 bool prof_enabled();
 void prof_begin(int slot, hipStream_t st, hipEvent_t* start);
-void prof_end(int slot, hipStream_t st, hipEvent_t start);
+void prof_end(int slot, hipStream_t st, hipEvent_t start, double work);
 void prof_work(int slot, double work);
 
 struct ProfScope {
@@ -56,14 +56,18 @@ struct ProfScope {
     hipStream_t st;
     hipEvent_t start = nullptr;
     bool on;
+    double w_ = 0.0;
     ProfScope(int s, hipStream_t stream) : slot(s), st(stream), on(prof_enabled()) {
         if (on) prof_begin(slot, st, &start);
     }
     void work(double w) {
-        if (on) prof_work(slot, w);
+        if (on) {
+            prof_work(slot, w);
+            w_ += w;
+        }
     }
     ~ProfScope() {
-        if (on) prof_end(slot, st, start);
+        if (on) prof_end(slot, st, start, w_);
     }
 };
 

@@ -91,6 +91,18 @@ __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const Con
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int mb = m0 + (wm * TM + tm) * 32 + 4 * lh;
+            // residual values of this 32 x 32 block: sixteen unconditional loads from clamped (always valid) addresses, all in
+            // flight before the first use -- inside the bounds test below each load would wait for the one before it
+            float rres[RES ? 16 : 1];
+            if constexpr (RES) {
+                const int nc = min(n, s.Cout - 1);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = mb + (i & 3) + 8 * (i >> 2);
+                    const size_t pix = (MODE == IN_DGRAD && rowtab) ? (size_t)rowtab[m - m0] : (size_t)min(m, M - 1);
+                    rres[i] = p.res[pix * s.Cout + nc];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int m = mb + (i & 3) + 8 * (i >> 2);
@@ -122,8 +134,8 @@ __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const Con
                         }
                     } else {
                         const size_t pix = (MODE == IN_DGRAD && rowtab) ? (size_t)rowtab[m - m0] : (size_t)m;
-                        const float rv = RES ? p.res[pix * s.Cout + n] : 0.f;
-                        p.y[pix * s.Cout + n] = ACT ? apply_act(v + bv + rv, p.act) : v;
+                        const float vr = RES ? v + rres[i] : v;
+                        p.y[pix * s.Cout + n] = ACT ? apply_act(vr + bv, p.act) : vr;
                     }
                 }
             }
@@ -167,7 +179,9 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
         stats = (m0 < p.stat_split && m0 + bm > p.stat_split) ? 2 : 1;
     }
     if (MODE == IN_DGRAD && p.ksplit <= 1) {
-        conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        // p.res: another gradient of the same tensor (a skip / downsample path's), added here instead of by an autograd pass
+        if (p.res) conv_epilogue_body<TM, TN, MODE, 0, false, true>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
+        else conv_epilogue_body<TM, TN, MODE, 0, false>(p, s, acc, m0, n0, wm, wn, lane, M, rowtab, bm);
     } else if (p.ksplit > 1) {       // (data gradients only split when their rows are plain pixels: stride 1, no upsample split)
         const int ln = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -761,7 +775,13 @@ int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int
 
 int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
                      int dact, float* dx_skip, int C1, void* stream) {
+    return dvs_conv2d_dgrad_res(dy, wt, dx, d, y_out, dact, dx_skip, C1, nullptr, stream);
+}
+
+int dvs_conv2d_dgrad_res(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
+                         int dact, float* dx_skip, int C1, const float* residual, void* stream) {
     DVS_REQUIRE(dy && wt && dx && d, "dvs_conv2d_dgrad: null pointer");
+    DVS_REQUIRE(!residual || (C1 == 0 && residual != dx), "dvs_conv2d_dgrad: a residual excludes the upsample+concat split and may not alias dx");
     DVS_REQUIRE(C1 == 0 || (d->stride == 1 && (d->H & 1) == 0 && (d->W & 1) == 0 && C1 <= d->Cin &&
                             (C1 == d->Cin || dx_skip != nullptr)),
                 "dvs_conv2d_dgrad: bad upsample+concat split");
@@ -791,8 +811,9 @@ int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv
     p.t.dact = dact;
     p.y2 = dx_skip;
     p.split_c1 = C1;
+    p.res = residual;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d->pad_mode == PAD_REFLECT && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+    if (!residual && d->pad_mode == PAD_REFLECT && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
         thin_dgrad(dy, wt, dx, y_out, dact, d->B, d->H, d->W, d->Cin, d->Cout, C1, dx_skip, st))
         return dvs::check_launch("dvs_conv2d_dgrad");      // 16-output-channel decoder layers: conv_thin.hip
     launch_mode<IN_DGRAD, false>(p, st, dvs::SLOT_CONV_DGRAD);

@@ -26,6 +26,7 @@ struct HeadParams {
     float* y;            // [B,H,W,Cout]   (stride 1, "same" size)
     const float* dy;     // backward: gradient of y (post-activation)
     float* dx;           // [B,H,W,Cin]
+    const float* dx_res; // optional [B,H,W,Cin]: another gradient of x, added to dx (dvs_conv2d_head_bwd_res)
     float* dw;           // [Cout][Ktot], atomics
     float* dbias;        // [Cout], atomics
     int B, H, W, Cin, Cout, k, pad, reflect, act;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(HNT) void head_dgrad_kernel(HeadParams p) {
             }
         }
     }
+    if (p.dx_res) acc += *reinterpret_cast<const f32x4*>(p.dx_res + (size_t)m * p.Cin + ci);
     *reinterpret_cast<f32x4*>(p.dx + (size_t)m * p.Cin + ci) = acc;
 }
 
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(HNT) void head_dgrad_rows_kernel(HeadParams p) {
             }
         }
     }
+    if (p.dx_res) acc += *reinterpret_cast<const f32x4*>(p.dx_res + (((size_t)b * p.H + y) * p.W + x) * p.Cin + ci);
     *reinterpret_cast<f32x4*>(p.dx + (((size_t)b * p.H + y) * p.W + x) * p.Cin + ci) = acc;
 }
 
@@ -520,11 +523,17 @@ int dvs_conv2d_head_fwd(const float* x, const float* w, const float* bias, float
 
 int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                         float* dbias, const dvs_conv_desc* d, int act, void* stream) {
+    return dvs_conv2d_head_bwd_res(x, w, y, dy, dx, dw, dbias, d, act, nullptr, stream);
+}
+
+int dvs_conv2d_head_bwd_res(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                            float* dbias, const dvs_conv_desc* d, int act, const float* dx_residual, void* stream) {
     DVS_REQUIRE(x && w && y && dy && dw, "dvs_conv2d_head_bwd: null pointer");
+    DVS_REQUIRE(!dx_residual || (dx && dx_residual != dx), "dvs_conv2d_head_bwd: the residual needs dx and may not alias it");
     HeadParams p{};
     int rc = fill(p, d, act, "dvs_conv2d_head_bwd");
     if (rc) return rc;
-    p.x = x; p.w = w; p.y = const_cast<float*>(y); p.dy = dy; p.dx = dx; p.dw = dw; p.dbias = dbias;
+    p.x = x; p.w = w; p.y = const_cast<float*>(y); p.dy = dy; p.dx = dx; p.dw = dw; p.dbias = dbias; p.dx_res = dx_residual;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dx) {
         rc = dispatch(p, 1, st);

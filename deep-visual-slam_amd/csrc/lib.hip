@@ -25,6 +25,7 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Pair {
     hipEvent_t a, b;
+    double work;
 };
 std::mutex g_mu;
 std::atomic<bool> g_on{false};
@@ -36,12 +37,17 @@ const char* kSlotNames[SLOT_COUNT] = {"chain_fwd_kernel", "chain_bwd_kernel", "a
                                       "conv_dgrad_kernel", "conv_wgrad_kernel", "bn_fwd_kernel", "bn_bwd_kernel",
                                       "attention_fwd_kernel", "attention_bwd_kernel"};
 
+// DVS_PROFILE_LOG=<path>: one line per recorded launch (slot, algorithmic work, milliseconds) in launch order per slot --
+// the per-layer view behind the per-slot totals (tools/per_launch.py)
+FILE* g_log = nullptr;
+
 void drain_locked(int slot) {
     for (Pair& p : g_pairs[slot]) {
         float ms = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             g_ms[slot] += ms;
             g_n[slot] += 1;
+            if (g_log) fprintf(g_log, "%s %.0f %.6f\n", kSlotNames[slot], p.work, ms);
         }
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -71,7 +77,7 @@ void prof_work(int slot, double work) {
     g_work[slot] += work;
 }
 
-void prof_end(int slot, hipStream_t st, hipEvent_t start) {
+void prof_end(int slot, hipStream_t st, hipEvent_t start, double work) {
     if (!start) return;
     hipEvent_t stop;
     if (hipEventCreate(&stop) != hipSuccess) {
@@ -80,7 +86,7 @@ void prof_end(int slot, hipStream_t st, hipEvent_t start) {
     }
     (void)hipEventRecord(stop, st);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_pairs[slot].push_back({start, stop});
+    g_pairs[slot].push_back({start, stop, work});
 }
 
 }  // namespace dvs
@@ -95,6 +101,11 @@ int dvs_profile_enable(int on) {
         dvs::g_n[s] = 0;
         dvs::g_work[s] = 0.0;
     }
+    if (on && !dvs::g_log) {
+        const char* path = getenv("DVS_PROFILE_LOG");
+        if (path && *path) dvs::g_log = fopen(path, "a");
+    }
+    if (dvs::g_log) fflush(dvs::g_log);
     dvs::g_on.store(on != 0);
     return DVS_OK;
 }
@@ -130,7 +141,7 @@ int dvs_set_deterministic(int on) {
 
 int dvs_get_deterministic(void) { return dvs::deterministic() ? 1 : 0; }
 
-int dvs_abi_version(void) { return 4; }
+int dvs_abi_version(void) { return 5; }
 
 const char* dvs_arch(void) { return "gfx950"; }
 

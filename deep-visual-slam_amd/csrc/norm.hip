@@ -329,6 +329,177 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
     }
 }
 
+// ---- stem tail: relu(bn1(conv1(x))) -> MaxPool2d(3, 2, 1) without the tensor in between (model/resnet_encoder.py:102-104) ----
+// Forward: one lane per (pooled pixel, 4 channels) reads the nine y values of its window, applies scale / shift / ReLU and keeps
+// the first maximum (torch's scan order, as maxpool_fwd_kernel in pool.hip); z is never written unless a caller needs it (DepthNet's
+// finest skip connection) -- then the lane also stores the 2x2 block of z its window owns (taps ky, kx in {1, 2}: every pixel
+// has exactly one owner).  fin = [G][4][C] (scale, shift, mean, invstd); group = image / (B / G).
+__global__ __launch_bounds__(NT) void bn_relu_maxpool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ fin,
+                                                                 float* __restrict__ z, float* __restrict__ pooled,
+                                                                 unsigned* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo,
+                                                                 int per_group) {
+    const int cv = C >> 2;
+    const size_t n = (size_t)B * Ho * Wo * cv;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        const int c4 = (int)(i % cv);
+        size_t pix = i / cv;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho), b = (int)(pix / Ho);
+        const float* tab = fin + (size_t)(b / per_group) * 4 * C + c4 * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(tab), sh = *reinterpret_cast<const f32x4*>(tab + C);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const size_t o = (((size_t)b * H + iy) * W + ix) * C + c4 * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = v[j] * sc[j] + sh[j];
+                    v[j] = a != a ? a : fmaxf(a, 0.f);              // NaN propagates, as in torch's relu / max_pool2d
+                }
+                if (z && ky >= 1 && kx >= 1) *reinterpret_cast<f32x4*>(z + o) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (v[j] > best[j] || v[j] != v[j]) {
+                        best[j] = v[j];
+                        bi = (bi & ~(0xffu << (8 * j))) | ((unsigned)t << (8 * j));
+                    }
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(pooled + i * 4) = best;
+        idx[i] = bi;
+    }
+}
+
+// Gradient of the pool's input at pixel (b, iy, ix), channels 4 c4 ..: gather over the at most four windows that contain it.
+__device__ __forceinline__ f32x4 pool_grad_at(const float* __restrict__ dpool, const unsigned* __restrict__ idx, int b, int iy, int ix,
+                                              int c4, int cv, int Ho, int Wo) {
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int oy_hi = (iy + 1) >> 1, ox_hi = (ix + 1) >> 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = oy_hi - a, ky = iy + 1 - 2 * oy;
+        if (oy < 0 || oy >= Ho || ky > 2) continue;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ox = ox_hi - c, kx = ix + 1 - 2 * ox;
+            if (ox < 0 || ox >= Wo || kx > 2) continue;
+            const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * cv + c4;
+            const unsigned w = idx[o];
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dpool + o * 4);
+            const unsigned t = (unsigned)(ky * 3 + kx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (((w >> (8 * j)) & 0xffu) == t) g[j] += d[j];
+        }
+    }
+    return g;
+}
+
+// Backward, pass 1 (the shape of bn_bwd_reduce_kernel): dz = pool gradient (gathered, never stored) [+ extra: the gradient of z's
+// other consumer], masked by the ReLU recomputed from y; partial sums of dz and dz * xhat per workgroup.
+__global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ idx,
+                                                                const float* __restrict__ extra, const float* __restrict__ y,
+                                                                const float* __restrict__ fin, float* __restrict__ partials, int M,
+                                                                int C, int H, int W, int Ho, int Wo, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
+    const int grp = blockIdx.y;
+    const size_t go = (size_t)grp * M * C;
+    y += go;
+    if (extra) extra += go;
+    fin += (size_t)grp * 4 * C;
+    partials += (size_t)grp * gridDim.x * 2 * C;
+    const int cv = C / 4, tid = threadIdx.x;
+    const int rl = tid / cv, cq = tid % cv, c = cq * 4, rlanes = NT / cv;
+    const int HW = H * W, b0 = grp * (M / HW);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(fin + c), sh = *reinterpret_cast<const f32x4*>(fin + C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(fin + 2 * C + c), is = *reinterpret_cast<const f32x4*>(fin + 3 * C + c);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, bsum = {0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + rl; r < r1; r += rlanes) {
+        const int bl = r / HW, rem = r - bl * HW, iy = rem / W, ix = rem - iy * W;
+        const size_t o = (size_t)r * cv + cq;
+        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[o];
+        f32x4 g = pool_grad_at(dpool, idx, b0 + bl, iy, ix, cq, cv, Ho, Wo);
+        if (extra) g += reinterpret_cast<const f32x4*>(extra)[o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
+            a[j] += gj;
+            bsum[j] += gj * (yy[j] - mu[j]) * is[j];
+        }
+    }
+    float* mine = red + tid * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = a[j];
+        mine[4 + j] = bsum[j];
+    }
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < rlanes; ++k) {
+            const float* o = red + (tid + k * cv) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] += o[j];
+                bsum[j] += o[4 + j];
+            }
+        }
+        float* row = partials + (size_t)blockIdx.x * 2 * C;
+        *reinterpret_cast<f32x4*>(row + c) = a;
+        *reinterpret_cast<f32x4*>(row + C + c) = bsum;
+    }
+}
+
+// Backward, pass 2: dy = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N) with dz gathered and masked as in pass 1.
+__global__ __launch_bounds__(NT) void bn_pool_bwd_apply_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ idx,
+                                                               const float* __restrict__ extra, const float* __restrict__ y,
+                                                               const float* __restrict__ fin, const float* __restrict__ gamma,
+                                                               const float* __restrict__ sums, float* __restrict__ dy, int M, int C,
+                                                               int H, int W, int Ho, int Wo, float inv_count,
+                                                               float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+    const int grp = blockIdx.y;
+    const size_t go = (size_t)grp * M * C;
+    y += go; dy += go;
+    if (extra) extra += go;
+    fin += (size_t)grp * 4 * C;
+    sums += (size_t)grp * 2 * C;
+    if (blockIdx.x == 0 && dgamma_acc) {
+        for (int c = threadIdx.x; c < C; c += NT) {
+            atomicAdd(dbeta_acc + c, sums[c]);
+            atomicAdd(dgamma_acc + c, sums[C + c]);
+        }
+    }
+    const int cv = C / 4, HW = H * W, b0 = grp * (M / HW);
+    const size_t n4 = (size_t)M * cv, stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        const int cq = (int)(i % cv), c = cq * 4, r = (int)(i / cv);
+        const int bl = r / HW, rem = r - bl * HW, iy = rem / W, ix = rem - iy * W;
+        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 g = pool_grad_at(dpool, idx, b0 + bl, iy, ix, cq, cv, Ho, Wo);
+        if (extra) g += reinterpret_cast<const f32x4*>(extra)[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(fin + c), sh = *reinterpret_cast<const f32x4*>(fin + C + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(fin + 2 * C + c), is = *reinterpret_cast<const f32x4*>(fin + 3 * C + c);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
+            const float xh = (yy[j] - mu[j]) * is[j];
+            o[j] = ga[j] * is[j] * (gj - s0[j] * inv_count - xh * s1[j] * inv_count);
+        }
+        reinterpret_cast<f32x4*>(dy)[i] = o;
+    }
+}
+
 inline unsigned stream_grid(size_t n4) {
     size_t b = (n4 + NT - 1) / NT;
     return (unsigned)(b > 2048 ? 2048 : (b == 0 ? 1 : b));     // 256 CUs x 8 blocks, grid-stride the rest
@@ -464,6 +635,52 @@ static int dvs_bn_bwd_apply_impl(const float* du, const float* y, const float* m
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
                        C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc, scale, shift);
     return dvs::check_launch("dvs_bn_bwd_apply");
+}
+
+int dvs_bn_relu_maxpool_fwd(const float* y, const float* fin, float* z, float* pooled, unsigned char* idx, int B, int H, int W, int C,
+                            int groups, void* stream) {
+    DVS_REQUIRE(y && fin && pooled && idx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && groups >= 1 && B % groups == 0,
+                "dvs_bn_relu_maxpool_fwd: bad argument");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t n4 = (size_t)B * Ho * Wo * (C / 4);
+    size_t blocks = (n4 + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_BN_FWD, st);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, y, fin, z, pooled,
+                       reinterpret_cast<unsigned*>(idx), B, H, W, C, Ho, Wo, B / groups);
+    return dvs::check_launch("dvs_bn_relu_maxpool_fwd");
+}
+
+int dvs_bn_relu_maxpool_bwd(const float* dpool, const unsigned char* idx, const float* dz_extra, const float* y, const float* fin,
+                            const float* gamma, float* sums, float* workspace, float* dy, int B, int H, int W, int C,
+                            float* dgamma_acc, float* dbeta_acc, int groups, void* stream) {
+    DVS_REQUIRE(dpool && idx && y && fin && sums && workspace && dy && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && groups >= 1 &&
+                    B % groups == 0, "dvs_bn_relu_maxpool_bwd: bad argument");
+    const int cv = C / 4;
+    DVS_REQUIRE(cv <= NT && (NT % cv) == 0, "dvs_bn_relu_maxpool_bwd: C/4 must divide 256 (C=%d)", C);
+    DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_relu_maxpool_bwd: gradient sinks come together");
+    const size_t M = (size_t)(B / groups) * H * W;
+    DVS_REQUIRE(M * cv < 2147483648ull, "dvs_bn_relu_maxpool_bwd: too many rows");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks, rpb;
+    bn_reduce_geometry(M, C, &blocks, &rpb);
+    const unsigned* ix = reinterpret_cast<const unsigned*>(idx);
+    {
+        dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+        hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dpool, ix,
+                           dz_extra, y, fin, workspace, (int)M, C, H, W, Ho, Wo, rpb);
+    }
+    const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
+    hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices, groups), dim3(NT), 0, st, workspace, sums, blocks,
+                       2 * C, rps);
+    {
+        dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(M * cv), groups), dim3(NT), 0, st, dpool, ix, dz_extra, y, fin,
+                           gamma, sums, dy, (int)M, C, H, W, Ho, Wo, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
+    }
+    return dvs::check_launch("dvs_bn_relu_maxpool_bwd");
 }
 
 }  // extern "C"

@@ -45,9 +45,10 @@ __global__ __launch_bounds__(PNT) void maxpool_fwd_kernel(const float* __restric
     }
 }
 
+// res (optional): another gradient of the pooled tensor (DepthNet's finest skip connection), added here
 __global__ __launch_bounds__(PNT) void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned* __restrict__ idx,
-                                                          float* __restrict__ dx, int B, int H, int W, int C, int Ho,
-                                                          int Wo) {
+                                                          float* __restrict__ dx, const float* __restrict__ res, int B, int H,
+                                                          int W, int C, int Ho, int Wo) {
     const int cv = C >> 2;
     const size_t n = (size_t)B * H * W * cv;
     for (size_t i = (size_t)blockIdx.x * PNT + threadIdx.x; i < n; i += (size_t)gridDim.x * PNT) {
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(PNT) void maxpool_bwd_kernel(const float* __restric
         pix /= W;
         const int iy = (int)(pix % H), b = (int)(pix / H);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (res) g = *reinterpret_cast<const f32x4*>(res + i * 4);
         // windows (oy, ox) with 2*oy - 1 + ky == iy, ky in 0..2
         const int oy_hi = (iy + 1) >> 1, ox_hi = (ix + 1) >> 1;
 #pragma unroll
@@ -128,11 +130,16 @@ int dvs_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int B, in
 }
 
 int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, void* stream) {
+    return dvs_maxpool3x3s2_bwd_res(dy, idx, dx, nullptr, B, H, W, C, stream);
+}
+
+int dvs_maxpool3x3s2_bwd_res(const float* dy, const unsigned char* idx, float* dx, const float* residual, int B, int H, int W,
+                             int C, void* stream) {
     DVS_REQUIRE(dy && dx && idx && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "dvs_maxpool3x3s2_bwd: bad argument");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const size_t n = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(pool_grid(n)), dim3(PNT), 0, static_cast<hipStream_t>(stream), dy,
-                       reinterpret_cast<const unsigned*>(idx), dx, B, H, W, C, Ho, Wo);
+                       reinterpret_cast<const unsigned*>(idx), dx, residual, B, H, W, C, Ho, Wo);
     return dvs::check_launch("dvs_maxpool3x3s2_bwd");
 }
 

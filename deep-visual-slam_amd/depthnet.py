@@ -57,5 +57,10 @@ class DepthNet(nn.Module):
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             x = self.convs[("upconv", i, 1)](x, skip=skip, upsample=True)
             if i in self.scales and self._wanted(i):
-                self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")
+                if i > 0:
+                    # x feeds this head and the next decoder level: it travels through the head's autograd node, whose
+                    # data-gradient kernel then adds the next level's gradient (no autograd accumulation pass)
+                    self.outputs[("disp", i)], x = self.convs[("dispconv", i)](x, act="sigmoid", passthrough=True)
+                else:
+                    self.outputs[("disp", i)] = self.convs[("dispconv", i)](x, act="sigmoid")
         return self.outputs

@@ -42,18 +42,23 @@ class batch_groups:
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, reflect_pad=0, act=None, x2=None, upsample=False,
-           planar_norm=None):
+           planar_norm=None, passthrough=False):
     """act(conv(pad(input), weight) + bias) where input is x, upsample2x(x) (upsample=True) or
     cat([upsample2x(x), x2], 1) (x2 given); reflect_pad=1 puts ReflectionPad2d(1) in front
     (model/layers.py:121-136); planar_norm=(scale, shift) is the encoder's conv1 on the raw planar image
-    with (x - 0.45) / 0.225 folded in (model/resnet_encoder.py:102-103)."""
+    with (x - 0.45) / 0.225 folded in (model/resnet_encoder.py:102-103).
+    passthrough: returns (y, x') -- x' is x, on the training path as a second output of this convolution's autograd node, so
+    that the gradient of x's NEXT consumer is added inside this convolution's data-gradient kernel."""
     _require_gpu(x, "conv2d")
     planar = planar_norm is not None
+    if passthrough and not (_PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad and not _lib.deterministic()
+                            and x2 is None and not upsample and not planar):
+        return conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2, upsample, planar_norm), x
     if _conv.supported(x, weight, x2, planar, upsample):
         return _conv.conv2d(x, weight, bias, stride, padding, reflect_pad, act, x2=x2, upsample=upsample,
-                            planar_norm=planar_norm)
+                            planar_norm=planar_norm, passthrough=passthrough)
     if _conv.head_supported(x, weight, stride, padding, reflect_pad, x2, upsample, planar):
-        return _conv.head_conv2d(x, weight, bias, padding, reflect_pad, act)
+        return _conv.head_conv2d(x, weight, bias, padding, reflect_pad, act, passthrough=passthrough)
     raise _lib.DvsError("conv2d: no gfx950 kernel for weight %s on input %s (stride %d, pad %d, reflect %d, concat %s, "
                         "upsample %s): channel counts must be multiples of 4 (or a 1/2/6/8-channel stride-1 head)"
                         % (tuple(weight.shape), tuple(x.shape), stride, padding, reflect_pad, x2 is not None, upsample))
@@ -120,14 +125,21 @@ def _eval_affine(bn):
 _PASSTHROUGH = os.environ.get("DVS_SKIP_PASSTHROUGH", "1") != "0"
 
 
+def passthrough_active(x, bn):
+    """The training path on which a tensor with several consumers is handed from one consumer's autograd node to the next
+    (x' = x as an extra output), so that their gradients are added inside the data-gradient kernels."""
+    return (_PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad and bn.training and not inference_mode(bn)
+            and not _lib.deterministic())
+
+
 def conv_bn_relu_with_identity(x, weight, bn, stride=1, padding=0):
-    """(relu(bn(conv(x))), x') for the first half of a BasicBlock without a downsample branch: x' is x, handed back as a second
-    output of the convolution's autograd node.  The block adds x' (not x) as its identity, so the skip path's gradient arrives in
-    that node's backward and is added in the data-gradient kernel's epilogue -- otherwise autograd sums the two gradients of x
-    with one more pass over the tensor (26 such passes, 0.64 ms, per VO step).  Outside the training path it is (conv_bn_act, x)."""
+    """(relu(bn(conv(x))), x') for the first half of a BasicBlock: x' is x, handed back as a second output of the convolution's
+    autograd node.  The block takes its identity (or its 1x1 downsample branch) from x' (not x), so the skip path's gradient
+    arrives in that node's backward and is added in the data-gradient kernel's epilogue -- otherwise autograd sums the two
+    gradients of x with one more pass over the tensor (26 such passes, 0.64 ms, per VO step for the identity blocks alone).
+    Outside the training path it is (conv_bn_act, x)."""
     from . import bn as _bn
-    if not (_PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad and bn.training and not inference_mode(bn)
-            and not _lib.deterministic() and _conv.supported(x, weight, None, False) and _bn.supported_c(weight.shape[0], bn)):
+    if not (passthrough_active(x, bn) and _conv.supported(x, weight, None, False) and _bn.supported_c(weight.shape[0], bn)):
         return conv_bn_act(x, weight, bn, stride, padding, relu=True), x
     _require_gpu(x, "conv_bn_act")
     G = _batch_groups
@@ -135,14 +147,20 @@ def conv_bn_relu_with_identity(x, weight, bn, stride=1, padding=0):
     return _bn.bn_act(y, bn, st, True, groups=G), xa
 
 
-def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None):
+def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, res=None, planar_norm=None, res_passthrough=False):
     """relu(bn(conv(x)) + residual') -- the conv -> BatchNorm2d -> (+identity) -> ReLU groups of torchvision's
     BasicBlock / stem (model/resnet_encoder.py:100-111).  `residual` is the identity tensor; `res` =
     (weight, bn, stride) describes the 1x1 downsample branch conv -> bn applied to `residual` instead.
     Training: the conv epilogue accumulates the batch statistics, BN + add + ReLU is one fused pass.
     eval() + no_grad: BatchNorm folded into the weights, one kernel per conv.
     eval() with autograd (validation loss without no_grad, frozen-BN fine-tuning): BatchNorm is a per-channel affine
-    map applied by the same BN kernels with fixed statistics; batch grouping is irrelevant there."""
+    map applied by the same BN kernels with fixed statistics; batch grouping is irrelevant there.
+    res_passthrough (with `res`): returns (z, residual') -- `residual` handed on as a second output of the downsample
+    convolution's autograd node (for one more consumer of the block input: DepthNet's skip connections)."""
+    if res_passthrough:
+        if res is not None and passthrough_active(residual, bn) and not _lib.deterministic():
+            return _conv_bn_act_ds_passthrough(x, weight, bn, stride, padding, relu, residual, res)
+        return conv_bn_act(x, weight, bn, stride, padding, relu, residual, res, planar_norm), residual
     _require_gpu(x, "conv_bn_act")
     from . import bn as _bn
     planar = planar_norm is not None
@@ -185,11 +203,44 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
     return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
 
 
+def _conv_bn_act_ds_passthrough(x, weight, bn, stride, padding, relu, residual, res):
+    """Training path of conv_bn_act with a downsample branch whose convolution also hands its input on (see conv_bn_act)."""
+    _require_gpu(x, "conv_bn_act")
+    from . import bn as _bn
+    if (not _conv.supported(x, weight, None, False) or not _conv.supported(residual, res[0])
+            or not _bn.supported_c(weight.shape[0], bn) or not _bn.supported_c(res[0].shape[0], res[1])):
+        return conv_bn_act(x, weight, bn, stride, padding, relu, residual, res), residual
+    G = _batch_groups
+    y, st = _conv.conv2d(x, weight, None, stride, padding, want_stats=G)
+    yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G, passthrough=True)
+    return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G), ra
+
+
+_STEM_TAIL = os.environ.get("DVS_STEM_TAIL", "1") != "0"
+
+
+def stem_conv_bn_relu_pool(x, weight, bn, planar_norm, need_z=True):
+    """(z, maxpool(z)) with z = relu(bn1(conv1((x - 0.45) / 0.225))) -- model/resnet_encoder.py:102-104.  Training: BatchNorm, ReLU
+    and the pool are ONE pass over conv1's output (bn.bn_relu_pool) and z is only materialised when `need_z` (DepthNet's finest
+    skip connection; PoseNet reads the last feature only, its z is returned as None).  Otherwise the separate operators."""
+    _require_gpu(x, "stem")
+    from . import bn as _bn
+    if not (_STEM_TAIL and bn.training and not inference_mode(bn) and not _lib.deterministic()
+            and _conv.supported(x, weight, None, True) and _bn.supported_c(weight.shape[0], bn)):
+        z = conv_bn_act(x, weight, bn, 2, 3, relu=True, planar_norm=planar_norm)
+        p, z = max_pool_3x3_s2(z, passthrough=True)
+        return z, p
+    G = _batch_groups
+    y, st = _conv.conv2d(x, weight, None, 2, 3, planar_norm=planar_norm, want_stats=G)
+    return _bn.bn_relu_pool(y, bn, st, groups=G, need_z=need_z)
+
+
 class _MaxPool3x3s2(torch.autograd.Function):
     """nn.MaxPool2d(3, 2, 1) on NHWC tensors (dvs_maxpool3x3s2_*): byte argmax forward, gather backward."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, passthrough=False):
+        x_in = x
         x = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -199,24 +250,37 @@ class _MaxPool3x3s2(torch.autograd.Function):
                    "dvs_maxpool3x3s2_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (B, C, H, W)
+        if passthrough:       # x' = x as a second output: the gradient of its other consumer is added in the backward kernel
+            ctx.set_materialize_grads(False)
+            return y, x_in.view_as(x_in)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxa=None):
+        if dy is None:
+            return dxa, None
         (idx,) = ctx.saved_tensors
         B, C, H, W = ctx.shape
-        dy = dy if dy.is_contiguous(memory_format=torch.channels_last) else dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _lib.check(_lib.lib().dvs_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B, H, W, C, _lib.stream()),
+        cl = torch.channels_last
+        dy = dy if dy.is_contiguous(memory_format=cl) else dy.contiguous(memory_format=cl)
+        if dxa is not None:
+            dxa = dxa if dxa.is_contiguous(memory_format=cl) else dxa.contiguous(memory_format=cl)
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32, memory_format=cl)
+        _lib.check(_lib.lib().dvs_maxpool3x3s2_bwd_res(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(),
+                                                       dxa.data_ptr() if dxa is not None else None, B, H, W, C, _lib.stream()),
                    "dvs_maxpool3x3s2_bwd")
-        return dx
+        return dx, None
 
 
-def max_pool_3x3_s2(x):
+def max_pool_3x3_s2(x, passthrough=False):
+    """passthrough: returns (y, x') with x' = x as a second output of the pool's autograd node."""
     _require_gpu(x, "max_pool")
     if x.shape[1] % 4 or x.dtype != torch.float32:
         raise _lib.DvsError("max_pool_3x3_s2: fp32 tensors with a multiple of 4 channels only (got %s %s)" % (x.dtype, tuple(x.shape)))
-    return _MaxPool3x3s2.apply(x)
+    if passthrough and _PASSTHROUGH and torch.is_grad_enabled() and x.requires_grad and not _lib.deterministic():
+        return _MaxPool3x3s2.apply(x, True)
+    y = _MaxPool3x3s2.apply(x)
+    return (y, x) if passthrough else y
 
 
 class _Upsample2x(torch.autograd.Function):

@@ -21,6 +21,7 @@ class PoseNet(nn.Module):
         self.stride = stride
         self.encoder = ResnetEncoder(num_layers=num_layers, pretrained=pretrained,
                                      num_input_images=num_input_images)
+        self.encoder.need_feature0 = False      # only feature[-1] is read below
         self.num_ch_enc = self.encoder.num_ch_enc
         self.convs = OrderedDict()
         self.convs[("squeeze")] = nn.Conv2d(self.num_ch_enc[-1], 256, 1)

@@ -28,13 +28,19 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        return self.forward_with_input(x)[0]
+
+    def forward_with_input(self, x):
+        """(block(x), x').  On the training path x' is x after it has travelled through the autograd nodes of its consumers
+        inside the block (conv1, then the downsample convolution): one more consumer of the block input -- DepthNet's skip
+        connection -- reads x', and every consumer's gradient is added in the next one's data-gradient kernel instead of by
+        autograd accumulation passes."""
+        # identity / downsample input taken from conv1's autograd node (nn_ops.conv_bn_relu_with_identity)
+        out, x = nn_ops.conv_bn_relu_with_identity(x, self.conv1.weight, self.bn1, self.stride, 1)
         if self.downsample is None:
-            # identity taken from conv1's autograd node (nn_ops.conv_bn_relu_with_identity): one pass less in the backward
-            out, x = nn_ops.conv_bn_relu_with_identity(x, self.conv1.weight, self.bn1, self.stride, 1)
-            return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x)
-        out = nn_ops.conv_bn_act(x, self.conv1.weight, self.bn1, self.stride, 1, relu=True)
+            return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x), x
         res = (self.downsample[0].weight, self.downsample[1], self.stride)
-        return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x, res=res)
+        return nn_ops.conv_bn_act(out, self.conv2.weight, self.bn2, 1, 1, relu=True, residual=x, res=res, res_passthrough=True)
 
 
 class ResNet(nn.Module):
@@ -88,6 +94,9 @@ class ResnetEncoder(nn.Module):
             raise NotImplementedError("only BasicBlock ResNets (18/34) are on the MI355X hot path; "
                                       "the reference trainer uses 18 (vo/train.py:67-93)")
         self.encoder = ResNet(_BLOCKS[num_layers], num_input_images=num_input_images)
+        # False: the caller never reads features[0] (PoseNet uses the last feature only), so the training forward does not
+        # materialise relu(bn1(conv1(x))) and hands out None in its place
+        self.need_feature0 = True
         if pretrained:
             self._load_imagenet(num_layers, num_input_images)
 
@@ -119,11 +128,16 @@ class ResnetEncoder(nn.Module):
             self._norm = (torch.full((nch,), 1.0 / 0.225, device=input_image.device),
                           torch.full((nch,), -0.45 / 0.225, device=input_image.device))
         scale, shift = self._norm
-        self.features.append(nn_ops.conv_bn_act(input_image, e.conv1.weight, e.bn1, 2, 3, relu=True,
-                                                planar_norm=(scale, shift)))
-        x = nn_ops.max_pool_3x3_s2(self.features[-1])
+        # bn1 + relu + maxpool in one pass on the training path; features[0] is None when nobody reads it (need_feature0)
+        z, x = nn_ops.stem_conv_bn_relu_pool(input_image, e.conv1.weight, e.bn1, (scale, shift), need_z=self.need_feature0)
+        self.features.append(z)
+        # a feature map has up to three consumers (the next layer's conv1 and downsample branch, DepthNet's skip connection):
+        # the tensor handed out as the feature is the one that has passed through the encoder-side consumers' autograd nodes
         for layer in (e.layer1, e.layer2, e.layer3, e.layer4):
-            for block in layer:
-                x = block(x)
+            for i, block in enumerate(layer):
+                if i == 0 and block.downsample is not None:
+                    x, self.features[-1] = block.forward_with_input(x)
+                else:
+                    x = block(x)
             self.features.append(x)
         return self.features

@@ -185,6 +185,13 @@ int dvs_reflect_fold(const float* g_padded, float* dx, float* dx_skip, int B, in
  *   channels [C1,Cin) are stored to dx_skip = [B,H,W,Cin-C1]; C1 == Cin (upsample only) needs no dx_skip. */
 int dvs_conv2d_dgrad(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
                      int dact, float* dx_skip, int C1, void* stream);
+/*   dvs_conv2d_dgrad_res (ABI 5): dx = data gradient + residual [B,H,W,Cin] (NULL = none; C1 must be 0).  Where a tensor feeds
+ *   several consumers -- a BasicBlock input read by conv1, the 1x1 downsample branch and, in DepthNet, the decoder's skip
+ *   connection (torchvision BasicBlock through model/resnet_encoder.py:94-111, model/depthnet.py:79-85) -- autograd would add
+ *   the consumers' gradients in one more pass over the tensor each; the gradient already computed is added in this kernel's
+ *   epilogue instead.  Same for dvs_conv2d_head_bwd_res (dx += dx_residual) and dvs_maxpool3x3s2_bwd_res below. */
+int dvs_conv2d_dgrad_res(const float* dy, const float* wt, float* dx, const dvs_conv_desc* d, const float* y_out,
+                         int dact, float* dx_skip, int C1, const float* residual, void* stream);
 int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
                      const dvs_conv_fusion* f, const float* y_out, int dact, void* stream);
 
@@ -196,6 +203,8 @@ int dvs_conv2d_head_fwd(const float* x, const float* w, const float* bias, float
                         void* stream);
 int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
                         float* dbias, const dvs_conv_desc* d, int act, void* stream);
+int dvs_conv2d_head_bwd_res(const float* x, const float* w, const float* y, const float* dy, float* dx, float* dw,
+                            float* dbias, const dvs_conv_desc* d, int act, const float* dx_residual, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1  the ResNet stem's MaxPool2d(kernel_size=3, stride=2, padding=1) on NHWC tensors
@@ -205,6 +214,9 @@ int dvs_conv2d_head_bwd(const float* x, const float* w, const float* y, const fl
  * ------------------------------------------------------------------------------------------- */
 int dvs_maxpool3x3s2_fwd(const float* x, float* y, unsigned char* idx, int B, int H, int W, int C, void* stream);
 int dvs_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int H, int W, int C, void* stream);
+/* dx = maxpool gradient + residual [B,H,W,C] (NULL = none): the stem output feeds the pool and DepthNet's finest skip. */
+int dvs_maxpool3x3s2_bwd_res(const float* dy, const unsigned char* idx, float* dx, const float* residual, int B, int H, int W,
+                             int C, void* stream);
 /* `upsample` of model/layers.py:196-199 (F.interpolate(scale_factor=2, mode="nearest")) as a standalone operator on NHWC
  * tensors: x, dx [B,H,W,C]; y, dy [B,2H,2W,C]; C % 4 == 0.  The backward is the 2x2 block sum.  (The decoder itself never
  * materialises the upsampled tensor: dvs_conv_fusion.x2 / C1 gather it inside the convolution.) */
@@ -253,6 +265,20 @@ int dvs_bn_bwd_reduce(const float* dz, const float* z, const float* y, const flo
 int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const float* invstd, const float* gamma,
                      const float* sums, float* dy, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups,
                      void* stream);
+/* Stem tail (ABI 5): relu(bn1(conv1(x))) -> MaxPool2d(3, 2, 1) of model/resnet_encoder.py:102-104 without the tensor in between.
+ *   fwd: y [B,H,W,C] = raw conv1 output, fin [G][4][C] = scale, shift, mean, invstd from dvs_bn_finalize (group = image / (B/G));
+ *        pooled [B,Ho,Wo,C] and idx (one byte per element, winning tap ky*3+kx, first maximum in scan order) as
+ *        dvs_maxpool3x3s2_fwd would give on z = relu(y*scale+shift); z [B,H,W,C] is written only when non-NULL (DepthNet's
+ *        finest skip connection reads it; PoseNet never does).
+ *   bwd: dz = maxpool gradient (gathered from dpool / idx, never stored) + dz_extra (NULL or [B,H,W,C]: the gradient of z's
+ *        other consumer), ReLU mask recomputed from y; sums [G][2][C] (zero-filled by the caller) receive sum(dz), sum(dz*xhat);
+ *        dy [B,H,W,C] = training-mode BatchNorm backward; dgamma_acc / dbeta_acc as in dvs_bn_bwd_apply.  workspace:
+ *        dvs_bn_bwd_workspace((B/G)*H*W, C, G) bytes.  C/4 must divide 256. */
+int dvs_bn_relu_maxpool_fwd(const float* y, const float* fin, float* z, float* pooled, unsigned char* idx, int B, int H, int W, int C,
+                            int groups, void* stream);
+int dvs_bn_relu_maxpool_bwd(const float* dpool, const unsigned char* idx, const float* dz_extra, const float* y, const float* fin,
+                            const float* gamma, float* sums, float* workspace, float* dy, int B, int H, int W, int C,
+                            float* dgamma_acc, float* dbeta_acc, int groups, void* stream);
 /* ReLU without a residual (bn1 of a BasicBlock, the stem): the mask z > 0 is recomputed from y with the forward's own
  * expression max(y*scale + shift, 0) (scale / shift = rows 0 / 1 of dvs_bn_fwd's `fin` table), so the backward neither reads z
  * nor writes / re-reads du: 5 tensor passes instead of 7.  `dz` takes du's place in the apply call. */

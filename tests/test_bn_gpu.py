@@ -107,3 +107,49 @@ def test_relu_mask_recomputed_from_y_equals_the_mask_from_z(gpu_device):
                 DB._YMASK = old
         for a, b in zip(*out):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,C,H,W,groups,need_z", [(4, 64, 24, 32, 1, True), (4, 64, 24, 32, 2, False), (2, 64, 15, 21, 1, True),
+                                                     (6, 16, 9, 10, 2, True), (2, 64, 240, 320, 1, False)])
+def test_stem_tail_fused_equals_bn_relu_then_maxpool(gpu_device, B, C, H, W, groups, need_z):
+    """relu(bn1(y)) -> MaxPool2d(3, 2, 1) in one pass (bn.bn_relu_pool: z not materialised unless asked for, the pool gradient
+    gathered inside the BatchNorm backward passes) against the separate operators (bn.bn_act + nn_ops.max_pool_3x3_s2) and,
+    through them, torch: outputs, running statistics, dy, d gamma, d beta; with a second consumer of z when need_z."""
+    import torch.nn as nn
+    from deep_visual_slam_amd import bn as DB, nn_ops
+    torch.manual_seed(11)
+    y0 = (torch.randn(B, C, H, W, device=gpu_device) * 1.5 + 0.3).contiguous(memory_format=torch.channels_last)
+    cot_p = torch.randn(B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1, device=gpu_device).contiguous(memory_format=torch.channels_last)
+    cot_z = torch.randn_like(y0)
+
+    def stats_of(y):
+        parts = y.chunk(groups, 0)
+        st = torch.stack([torch.stack([p.sum((0, 2, 3)), (p * p).sum((0, 2, 3))]) for p in parts])
+        return st if groups > 1 else st[0]
+
+    def run(fused):
+        m = nn.BatchNorm2d(C).to(gpu_device).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.linspace(0.5, 1.5, C)); m.bias.copy_(torch.linspace(-0.4, 0.4, C))
+        y = y0.clone().requires_grad_(True)
+        st = stats_of(y.detach())
+        if fused:
+            z, p = DB.bn_relu_pool(y, m, st, groups=groups, need_z=need_z)
+        else:
+            z = DB.bn_act(y, m, st, True, groups=groups)
+            p = nn_ops.max_pool_3x3_s2(z)
+        loss = (p * cot_p).sum()
+        if need_z:
+            loss = loss + (z * cot_z).sum()
+        g = torch.autograd.grad(loss, [y, m.weight, m.bias])
+        return p.detach(), (z.detach() if need_z else None), g, m.running_mean.clone(), m.running_var.clone()
+
+    p1, z1, g1, rm1, rv1 = run(True)
+    p0, z0, g0, rm0, rv0 = run(False)
+    assert rel(p1, p0) < 1e-6          # (scale / shift come from two kernels whose fused multiply-adds may round differently)
+    if need_z:
+        assert rel(z1, z0) < 1e-6
+    assert torch.allclose(rm1, rm0) and torch.allclose(rv1, rv0)
+    for a, r, nm in zip(g1, g0, ("dy", "dgamma", "dbeta")):
+        err = float((a - r).abs().max() / (r.abs().max() + 1e-30))
+        assert err < 2e-5, (nm, err)

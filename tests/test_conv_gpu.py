@@ -164,3 +164,77 @@ def test_head_conv(gpu_device, cin, cout, k, refl, act, H, W):
     g = torch.autograd.grad(y, [x, w, b], cot)
     for a, r, nm in zip(g, g_ref, ("dx", "dw", "db")):
         assert a.shape == r.shape and relmax(a, r) < 1e-4, (nm, relmax(a, r))
+
+
+# ---- fan-in gradients added inside the data-gradient kernels (dvs_conv2d_dgrad_res / _head_bwd_res / maxpool _bwd_res)
+RES_CASES = [
+    # name, B, Cin, Cout, k, stride, pad, H, W      (the encoder's consumers of a block input / feature map)
+    ("3x3_s2", 2, 64, 128, 3, 2, 1, 24, 40),        # conv1 of a downsample block
+    ("1x1_s2", 2, 64, 128, 1, 2, 0, 24, 40),        # its downsample branch
+    ("3x3_s2_deep_splitk", 2, 256, 512, 3, 2, 1, 8, 12),
+    ("3x3_s1_direct", 1, 20, 36, 3, 1, 1, 11, 17),  # a stride-1 layer the Winograd kernel does not take (small K split path)
+    ("1x1_s2_odd", 1, 64, 128, 1, 2, 0, 15, 21),
+]
+
+
+@pytest.mark.parametrize("case", RES_CASES, ids=[c[0] for c in RES_CASES])
+def test_dgrad_with_residual(gpu_device, case):
+    """dx = conv data gradient + residual, in one kernel, against torch's data gradient plus the same tensor."""
+    from deep_visual_slam_amd import conv as DC
+    name, B, ci, co, k, s, p, H, W = case
+    torch.manual_seed(3)
+    x = torch.randn(B, ci, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, ci, k, k, device=gpu_device) * (2.0 / (ci * k * k)) ** 0.5).contiguous(memory_format=CL)
+    y_ref = F.conv2d(x, w, None, s, p)
+    cot = torch.randn_like(y_ref).contiguous(memory_format=CL)
+    res = torch.randn_like(x).contiguous(memory_format=CL)
+    (dx_ref,) = torch.autograd.grad(y_ref, [x], cot)
+    dx = DC.conv2d_dgrad(cot, w, tuple(x.shape), s, p, False, residual=res)
+    assert relmax(dx, dx_ref + res) < 1e-4
+    dx0 = DC.conv2d_dgrad(cot, w, tuple(x.shape), s, p, False)
+    assert relmax(dx0, dx_ref) < 1e-4
+    with pytest.raises(Exception):
+        DC.conv2d_dgrad(cot, w, tuple(x.shape), s, p, False, residual=res[:, :4])
+
+
+def test_passthrough_nodes_add_fan_in_gradients(gpu_device):
+    """A tensor with three consumers wired as conv1 -> downsample conv -> extra consumer through passthrough outputs, a head
+    with a passthrough, and the pool with a passthrough: same gradients as plain autograd accumulation."""
+    from deep_visual_slam_amd import conv as DC, nn_ops
+    torch.manual_seed(4)
+    B, H, W = 2, 16, 24
+    x = torch.randn(B, 64, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w1 = (torch.randn(128, 64, 3, 3, device=gpu_device) * 0.05).contiguous(memory_format=CL).requires_grad_(True)
+    wd = (torch.randn(128, 64, 1, 1, device=gpu_device) * 0.1).contiguous(memory_format=CL).requires_grad_(True)
+    wh = (torch.randn(1, 64, 3, 3, device=gpu_device) * 0.05).contiguous(memory_format=CL).requires_grad_(True)
+    bh = torch.zeros(1, device=gpu_device, requires_grad=True)
+
+    def run(passthrough):
+        if passthrough:
+            y1, xa = DC.conv2d(x, w1, None, 2, 1, passthrough=True)
+            yd, xb = DC.conv2d(xa, wd, None, 2, 0, passthrough=True)
+            yh, xc = DC.head_conv2d(xb, wh, bh, 0, 1, "sigmoid", passthrough=True)
+            yp, xe = nn_ops._MaxPool3x3s2.apply(xc, True)
+            extra = xe
+        else:
+            y1 = DC.conv2d(x, w1, None, 2, 1)
+            yd = DC.conv2d(x, wd, None, 2, 0)
+            yh = DC.head_conv2d(x, wh, bh, 0, 1, "sigmoid")
+            yp = nn_ops._MaxPool3x3s2.apply(x)
+            extra = x
+        loss = (y1 * c1).sum() + (yd * cd).sum() + (yh * ch).sum() + (yp * cp).sum() + (extra * ce).sum()
+        return torch.autograd.grad(loss, [x, w1, wd, wh, bh])
+
+    c1 = torch.randn(B, 128, H // 2, W // 2, device=gpu_device).contiguous(memory_format=CL)
+    cd = torch.randn_like(c1)
+    ch = torch.randn(B, 1, H, W, device=gpu_device).contiguous(memory_format=CL)
+    cp = torch.randn(B, 64, H // 2, W // 2, device=gpu_device).contiguous(memory_format=CL)
+    ce = torch.randn_like(x)
+    g_ref = run(False)
+    g = run(True)
+    for a, r, nm in zip(g, g_ref, ("dx", "dw1", "dwd", "dwh", "dbh")):
+        assert relmax(a, r) < 2e-5, (nm, relmax(a, r))
+    # an unused head output (single-scale training): the passthrough gradient still arrives
+    yh, xc = DC.head_conv2d(x, wh, bh, 0, 1, "sigmoid", passthrough=True)
+    (gx,) = torch.autograd.grad((xc * ce).sum(), [x])
+    assert relmax(gx, ce) < 1e-6

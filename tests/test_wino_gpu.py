@@ -271,3 +271,30 @@ def test_identity_passthrough_adds_the_skip_gradient_in_the_data_gradient():
     _, xa2 = DC.conv2d(x2, wt.detach(), None, 1, 1, passthrough=True)
     (xa2 * cot_s).sum().backward()
     assert torch.equal(x2.grad, cot_s)
+
+
+@pytest.mark.parametrize("B,c,h,w", [(24, 256, 15, 20), (2, 256, 15, 20), (3, 64, 9, 11)])
+def test_bias_relu_layer_autograd_matches_torch(B, c, h, w):
+    """PoseNet's decoder convolutions (Conv2d(256, 256, 3, 1, 1) + ReLU, model/posenet_single.py:160-164, 189-197): bias and ReLU
+    in the Winograd epilogue, dZ = dY * [Y > 0] and the bias gradient from one pre-activation pass, data and weight gradient on
+    the Winograd kernels."""
+    from deep_visual_slam_amd import conv as DC
+    x, wt = _mk(B, c, c, h, w, seed=5)
+    b = (torch.randn(c, device="cuda") * 0.3)
+    x.requires_grad_(True); wt.requires_grad_(True); b.requires_grad_(True)
+    y = DC.conv2d(x, wt, b, 1, 1, act="relu")
+    assert y.grad_fn is not None and y.is_contiguous(memory_format=CL)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, wt, b))
+    y64 = F.relu(F.conv2d(x64, w64, b64, 1, 1))
+    y64.backward(gy.double())
+    assert _rel(y, y64.detach()) < TOL
+    # a pre-activation within rounding of zero may fall on the other side of the ReLU: compare where the fp64 value is clear of it
+    pre = F.conv2d(x64.detach(), w64.detach(), b64.detach(), 1, 1)
+    flips = ((y > 0) != (pre > 0)).sum().item()
+    assert flips <= 1e-5 * y.numel()
+    if flips == 0:
+        assert _rel(x.grad, x64.grad) < TOL and _rel(wt.grad, w64.grad) < 2e-5 and _rel(b.grad, b64.grad) < 2e-5
+    else:
+        assert _rel(x.grad, x64.grad) < 1e-3 and _rel(wt.grad, w64.grad) < 1e-3 and _rel(b.grad, b64.grad) < 1e-3
