@@ -377,63 +377,88 @@ __global__ __launch_bounds__(NT) void bn_relu_maxpool_fwd_kernel(const float* __
     }
 }
 
-// Gradient of the pool's input at pixel (b, iy, ix), channels 4 c4 ..: gather over the at most four windows that contain it.
-__device__ __forceinline__ f32x4 pool_grad_at(const float* __restrict__ dpool, const unsigned* __restrict__ idx, int b, int iy, int ix,
-                                              int c4, int cv, int Ho, int Wo) {
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    const int oy_hi = (iy + 1) >> 1, ox_hi = (ix + 1) >> 1;
+// Backward of the stem tail.  A lane owns one 2x2 block of input pixels (the block the pooled pixel (oy, ox) "owns") and four
+// channels: the four windows that can reach those pixels -- (oy..oy+1, ox..ox+1) -- are loaded once (4 tap words, 4 gradient
+// vectors) for all four pixels, every load is unconditional from a clamped address (all in flight together), and pixel (a, c) of
+// the block receives window (a', c') iff a' <= a, c' <= c and its winning tap is ((a + 1 - 2a') * 3 + (c + 1 - 2c')).
+struct PoolBlock {
+    f32x4 g[4];       // masked dz of the pixels (a, c) = (0,0) (0,1) (1,0) (1,1); zero where the pixel does not exist
+    f32x4 y[4];
+    size_t o[4];      // float4 index of the pixel in y / dy
+    bool ok[4];
+};
+
+__device__ __forceinline__ void pool_block_load(PoolBlock& k, const float* __restrict__ dpool, const unsigned* __restrict__ idx,
+                                                const float* __restrict__ extra, const float* __restrict__ y, f32x4 sc, f32x4 sh,
+                                                int b, int oy, int ox, int cq, int cv, int H, int W, int Ho, int Wo) {
+    unsigned w[4];
+    f32x4 d[4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int oy = oy_hi - a, ky = iy + 1 - 2 * oy;
-        if (oy < 0 || oy >= Ho || ky > 2) continue;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ox = ox_hi - c, kx = ix + 1 - 2 * ox;
-            if (ox < 0 || ox >= Wo || kx > 2) continue;
-            const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * cv + c4;
-            const unsigned w = idx[o];
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dpool + o * 4);
-            const unsigned t = (unsigned)(ky * 3 + kx);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (((w >> (8 * j)) & 0xffu) == t) g[j] += d[j];
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int wy = oy + (q >> 1), wx = ox + (q & 1);
+        const bool wok = wy < Ho && wx < Wo;
+        const size_t o = (((size_t)b * Ho + min(wy, Ho - 1)) * Wo + min(wx, Wo - 1)) * cv + cq;
+        w[q] = wok ? idx[o] : 0xffffffffu;                  // tap 255 never matches
+        d[q] = reinterpret_cast<const f32x4*>(dpool)[o];
     }
-    return g;
+    f32x4 e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
+        k.ok[q] = iy < H && ix < W;
+        k.o[q] = (((size_t)b * H + min(iy, H - 1)) * W + min(ix, W - 1)) * cv + cq;
+        k.y[q] = reinterpret_cast<const f32x4*>(y)[k.o[q]];
+        if (extra) e[q] = reinterpret_cast<const f32x4*>(extra)[k.o[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int a = q >> 1, c = q & 1;
+        f32x4 g = extra ? e[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a2 = 0; a2 <= a; ++a2)
+#pragma unroll
+            for (int c2 = 0; c2 <= c; ++c2) {
+                const unsigned t = (unsigned)((a + 1 - 2 * a2) * 3 + (c + 1 - 2 * c2));
+                const unsigned ww = w[a2 * 2 + c2];
+                const f32x4 dd = d[a2 * 2 + c2];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (((ww >> (8 * j)) & 0xffu) == t) g[j] += dd[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = (k.ok[q] && k.y[q][j] * sc[j] + sh[j] > 0.f) ? g[j] : 0.f;
+        k.g[q] = g;
+    }
 }
 
-// Backward, pass 1 (the shape of bn_bwd_reduce_kernel): dz = pool gradient (gathered, never stored) [+ extra: the gradient of z's
-// other consumer], masked by the ReLU recomputed from y; partial sums of dz and dz * xhat per workgroup.
+// Pass 1 (the shape of bn_bwd_reduce_kernel, rows = 2x2 blocks): partial sums of dz and dz * xhat per workgroup.
 __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ idx,
                                                                 const float* __restrict__ extra, const float* __restrict__ y,
-                                                                const float* __restrict__ fin, float* __restrict__ partials, int M,
-                                                                int C, int H, int W, int Ho, int Wo, int rows_per_block) {
+                                                                const float* __restrict__ fin, float* __restrict__ partials, int Mb,
+                                                                int C, int H, int W, int Ho, int Wo, int per_group,
+                                                                int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
     const int grp = blockIdx.y;
-    const size_t go = (size_t)grp * M * C;
-    y += go;
-    if (extra) extra += go;
     fin += (size_t)grp * 4 * C;
     partials += (size_t)grp * gridDim.x * 2 * C;
     const int cv = C / 4, tid = threadIdx.x;
     const int rl = tid / cv, cq = tid % cv, c = cq * 4, rlanes = NT / cv;
-    const int HW = H * W, b0 = grp * (M / HW);
+    const int HWo = Ho * Wo, b0 = grp * per_group;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(fin + c), sh = *reinterpret_cast<const f32x4*>(fin + C + c);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(fin + 2 * C + c), is = *reinterpret_cast<const f32x4*>(fin + 3 * C + c);
     f32x4 a = {0.f, 0.f, 0.f, 0.f}, bsum = {0.f, 0.f, 0.f, 0.f};
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(Mb, r0 + rows_per_block);
     for (int r = r0 + rl; r < r1; r += rlanes) {
-        const int bl = r / HW, rem = r - bl * HW, iy = rem / W, ix = rem - iy * W;
-        const size_t o = (size_t)r * cv + cq;
-        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[o];
-        f32x4 g = pool_grad_at(dpool, idx, b0 + bl, iy, ix, cq, cv, Ho, Wo);
-        if (extra) g += reinterpret_cast<const f32x4*>(extra)[o];
+        const int bl = r / HWo, rem = r - bl * HWo, oy = rem / Wo, ox = rem - oy * Wo;
+        PoolBlock k;
+        pool_block_load(k, dpool, idx, extra, y, sc, sh, b0 + bl, oy, ox, cq, cv, H, W, Ho, Wo);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gj = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
-            a[j] += gj;
-            bsum[j] += gj * (yy[j] - mu[j]) * is[j];
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] += k.g[q][j];
+                bsum[j] += k.g[q][j] * (k.y[q][j] - mu[j]) * is[j];
+            }
     }
     float* mine = red + tid * 8;
 #pragma unroll
@@ -443,8 +468,8 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __r
     }
     __syncthreads();
     if (rl == 0) {
-        for (int k = 1; k < rlanes; ++k) {
-            const float* o = red + (tid + k * cv) * 8;
+        for (int k2 = 1; k2 < rlanes; ++k2) {
+            const float* o = red + (tid + k2 * cv) * 8;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[j] += o[j];
@@ -457,17 +482,14 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __r
     }
 }
 
-// Backward, pass 2: dy = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N) with dz gathered and masked as in pass 1.
+// Pass 2: dy = gamma * invstd * (dz - sum_dz / N - xhat * sum_dz_xhat / N) for the four pixels of the block.
 __global__ __launch_bounds__(NT) void bn_pool_bwd_apply_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ idx,
                                                                const float* __restrict__ extra, const float* __restrict__ y,
                                                                const float* __restrict__ fin, const float* __restrict__ gamma,
-                                                               const float* __restrict__ sums, float* __restrict__ dy, int M, int C,
-                                                               int H, int W, int Ho, int Wo, float inv_count,
+                                                               const float* __restrict__ sums, float* __restrict__ dy, int Mb, int C,
+                                                               int H, int W, int Ho, int Wo, int per_group, float inv_count,
                                                                float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
     const int grp = blockIdx.y;
-    const size_t go = (size_t)grp * M * C;
-    y += go; dy += go;
-    if (extra) extra += go;
     fin += (size_t)grp * 4 * C;
     sums += (size_t)grp * 2 * C;
     if (blockIdx.x == 0 && dgamma_acc) {
@@ -476,27 +498,29 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_apply_kernel(const float* __re
             atomicAdd(dgamma_acc + c, sums[C + c]);
         }
     }
-    const int cv = C / 4, HW = H * W, b0 = grp * (M / HW);
-    const size_t n4 = (size_t)M * cv, stride = (size_t)gridDim.x * NT;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
-        const int cq = (int)(i % cv), c = cq * 4, r = (int)(i / cv);
-        const int bl = r / HW, rem = r - bl * HW, iy = rem / W, ix = rem - iy * W;
-        const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
-        f32x4 g = pool_grad_at(dpool, idx, b0 + bl, iy, ix, cq, cv, Ho, Wo);
-        if (extra) g += reinterpret_cast<const f32x4*>(extra)[i];
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(fin + c), sh = *reinterpret_cast<const f32x4*>(fin + C + c);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(fin + 2 * C + c), is = *reinterpret_cast<const f32x4*>(fin + 3 * C + c);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        f32x4 ga = {1.f, 1.f, 1.f, 1.f};
-        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
-        f32x4 o;
+    const int cv = C / 4, HWo = Ho * Wo, b0 = grp * per_group;
+    const int cq = threadIdx.x % cv, c = cq * 4;            // cv divides NT: a lane's channels are the same in every iteration
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(fin + c), sh = *reinterpret_cast<const f32x4*>(fin + C + c);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(fin + 2 * C + c), is = *reinterpret_cast<const f32x4*>(fin + 3 * C + c);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const size_t n = (size_t)Mb * cv, stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / cv);
+        const int bl = r / HWo, rem = r - bl * HWo, oy = rem / Wo, ox = rem - oy * Wo;
+        PoolBlock k;
+        pool_block_load(k, dpool, idx, extra, y, sc, sh, b0 + bl, oy, ox, cq, cv, H, W, Ho, Wo);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gj = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
-            const float xh = (yy[j] - mu[j]) * is[j];
-            o[j] = ga[j] * is[j] * (gj - s0[j] * inv_count - xh * s1[j] * inv_count);
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (k.y[q][j] - mu[j]) * is[j];
+                o[j] = ga[j] * is[j] * (k.g[q][j] - s0[j] * inv_count - xh * s1[j] * inv_count);
+            }
+            if (k.ok[q]) reinterpret_cast<f32x4*>(dy)[k.o[q]] = o;
         }
-        reinterpret_cast<f32x4*>(dy)[i] = o;
     }
 }
 
@@ -661,24 +685,25 @@ int dvs_bn_relu_maxpool_bwd(const float* dpool, const unsigned char* idx, const 
     DVS_REQUIRE(cv <= NT && (NT % cv) == 0, "dvs_bn_relu_maxpool_bwd: C/4 must divide 256 (C=%d)", C);
     DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_relu_maxpool_bwd: gradient sinks come together");
     const size_t M = (size_t)(B / groups) * H * W;
-    DVS_REQUIRE(M * cv < 2147483648ull, "dvs_bn_relu_maxpool_bwd: too many rows");
+    DVS_REQUIRE((size_t)B * H * W * cv < 2147483648ull, "dvs_bn_relu_maxpool_bwd: too many elements");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t Mb = (size_t)(B / groups) * Ho * Wo;     // 2x2 blocks per group (one per pooled pixel)
     hipStream_t st = static_cast<hipStream_t>(stream);
     int blocks, rpb;
-    bn_reduce_geometry(M, C, &blocks, &rpb);
+    bn_reduce_geometry(Mb, C, &blocks, &rpb);             // <= the partial rows dvs_bn_bwd_workspace(M, C, groups) provides
     const unsigned* ix = reinterpret_cast<const unsigned*>(idx);
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
         hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dpool, ix,
-                           dz_extra, y, fin, workspace, (int)M, C, H, W, Ho, Wo, rpb);
+                           dz_extra, y, fin, workspace, (int)Mb, C, H, W, Ho, Wo, B / groups, rpb);
     }
     const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
     hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices, groups), dim3(NT), 0, st, workspace, sums, blocks,
                        2 * C, rps);
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
-        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(M * cv), groups), dim3(NT), 0, st, dpool, ix, dz_extra, y, fin,
-                           gamma, sums, dy, (int)M, C, H, W, Ho, Wo, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
+        hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(Mb * cv), groups), dim3(NT), 0, st, dpool, ix, dz_extra, y, fin,
+                           gamma, sums, dy, (int)Mb, C, H, W, Ho, Wo, B / groups, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
     }
     return dvs::check_launch("dvs_bn_relu_maxpool_bwd");
 }
