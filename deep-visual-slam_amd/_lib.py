@@ -64,6 +64,7 @@ _SIGNATURES = {
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),
+    "dvs_conv3x3_wino_fwd_slots": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp]),
     "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv2d_pack_wt_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_reflect_fold": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
@@ -84,6 +85,10 @@ _SIGNATURES = {
     "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_bn_fwd": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_bn_finalize_slots": (C.c_int, [_vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp,
+                                        C.c_int, _vp]),
+    "dvs_bn_fwd_slots": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_apply_fwd": (C.c_int, [_vp] * 7 + [C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_bwd_workspace": (C.c_size_t, [C.c_size_t, C.c_int, C.c_int]),
     "dvs_bn_bwd_reduce": (C.c_int, [_vp] * 8 + [C.c_size_t, C.c_int, C.c_int, _vp]),

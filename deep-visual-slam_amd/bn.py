@@ -26,6 +26,7 @@ def _finalize_groups(stats, count, bn, groups):
     running statistics and num_batches_tracked are updated as G successive forward calls of nn.BatchNorm2d in
     training mode would have done."""
     C = stats.shape[-1]
+    slots = stats.shape[0] if stats.dim() == 4 else 1        # [slots][G][2][C]: copies the Winograd forward spread its atomics over
     out = torch.empty(groups, 4, C, device=stats.device, dtype=torch.float32)
     train_stats = bn.training and bn.track_running_stats
     nbt = bn.num_batches_tracked if train_stats else None
@@ -33,7 +34,7 @@ def _finalize_groups(stats, count, bn, groups):
         raise _lib.DvsError("bn: num_batches_tracked must be an int64 GPU tensor")
     if train_stats:
         _nn_generation_bump()
-    check(_lib.lib().dvs_bn_finalize(stats.data_ptr(), float(count), ptr(bn.weight), ptr(bn.bias),
+    check(_lib.lib().dvs_bn_finalize_slots(stats.data_ptr(), slots, float(count), ptr(bn.weight), ptr(bn.bias),
                                      ptr(bn.running_mean) if train_stats else None,
                                      ptr(bn.running_var) if train_stats else None,
                                      float(bn.momentum if bn.momentum is not None else 0.1), float(bn.eps),
@@ -55,14 +56,15 @@ class _BNAct(torch.autograd.Function):
         M = B * H * W // groups                       # rows per group
         z = torch.empty_like(y)
         stats, count, rmean, rvar, momentum, eps, nbt = stat_args
+        slots = stats.shape[0] if stats.dim() == 4 else 1    # [slots][G][2][C] from the Winograd forward: added up in the kernel
         fin = torch.empty(groups, 4, C, device=y.device, dtype=torch.float32)
         # group g = rows [g M, (g + 1) M) with row g of the [G][.][C] tables
-        check(l.dvs_bn_fwd(y.data_ptr(), stats.data_ptr(), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+        check(l.dvs_bn_fwd_slots(y.data_ptr(), stats.data_ptr(), slots, float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
                            float(momentum), float(eps), nbt.data_ptr() if nbt is not None else None, fin.data_ptr(),
                            residual.data_ptr() if residual is not None else None,
                            res_fin[0, 0].data_ptr() if res_fin is not None else None,
                            res_fin[0, 1].data_ptr() if res_fin is not None else None,
-                           z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_fwd")
+                                 z.data_ptr(), M, C, int(relu), groups, _lib.stream()), "dvs_bn_fwd")
         ctx.relu, ctx.groups = relu, groups
         ctx.affine = (gamma, beta, res_gamma, res_beta)          # only to find their gradient sinks in backward
         # ReLU without a residual: the backward recomputes the mask from y (dvs_bn_bwd_*_ymask) and does not need z
@@ -190,7 +192,7 @@ def bn_relu_pool(y, bn, stats, groups=1, need_z=True):
         raise _lib.DvsError("bn_relu_pool: batch %d does not split into %d groups" % (B, groups))
     count = (B // groups) * H * W
     y = y if y.is_contiguous(memory_format=CL) else y.contiguous(memory_format=CL)
-    st = stats if stats.dim() == 3 else stats.unsqueeze(0)
+    st = stats if stats.dim() >= 3 else stats.unsqueeze(0)
     fin = _finalize_groups(st, count, bn, groups)
     out = _BNReluPool.apply(y, bn.weight, bn.bias, fin, groups, bool(need_z))
     return (out[1], out[0]) if need_z else (None, out)

@@ -258,7 +258,10 @@ def _wino_weight(w, weight, flip):
     return ent[int(flip)]
 
 
-def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None, bias=None, relu=False):
+STAT_SLOTS = int(os.environ.get("DVS_WINO_STAT_SLOTS", "16"))     # copies of the statistics table the Winograd forward spreads its atomics over
+
+
+def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None, bias=None, relu=False, stat_slots=1):
     """y = [relu](conv3x3(x, weight) [+ bias]) (stride 1, zero pad 1) on the Winograd kernel; flip: the data gradient of that
     convolution, x = dY [B,Cout,H,W] -> dX [B,Cin,H,W].  `weight` must be the parameter object itself (the operand cache is pinned to it)."""
     x, w = _nhwc(x), _nhwc(weight)
@@ -273,9 +276,10 @@ def conv3x3_wino(x, weight, stats=None, stat_groups=0, flip=False, residual=None
         residual = _nhwc(residual)
         if tuple(residual.shape) != tuple(y.shape):
             raise _lib.DvsError("conv3x3_wino: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    check(_lib.lib().dvs_conv3x3_wino_fwd(x.data_ptr(), u.data_ptr(), ptr(bias), residual.data_ptr() if residual is not None else None,
-                                          y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0,
-                                          B, H, W, k, n, int(bool(relu)), int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
+    # stat_slots > 1: stats is [stat_slots][G][2][N]; the BatchNorm kernels add the copies up (bn.bn_act)
+    check(_lib.lib().dvs_conv3x3_wino_fwd_slots(x.data_ptr(), u.data_ptr(), ptr(bias), residual.data_ptr() if residual is not None else None,
+                                                y.data_ptr(), ptr(stats), stat_groups if stats is not None else 0, int(stat_slots),
+                                                B, H, W, k, n, int(bool(relu)), int(flip), _lib.stream()), "dvs_conv3x3_wino_fwd")
     return y
 
 
@@ -412,6 +416,7 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
     return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
+STATS_SLOTTED = 4      # flag in conv2d(want_stats=G | STATS_SLOTTED): the statistics may come back as [slots][G][2][C]
 _PREACT = os.environ.get("DVS_CONV_PREACT", "1") != "0"
 _PADDED = os.environ.get("DVS_CONV_PADDED_DGRAD", "1") != "0"
 
@@ -425,8 +430,9 @@ class _Conv2d(torch.autograd.Function):
         stride, pad, reflect, act, planar, scale, shift, want_stats = opts[:8]
         passthrough = len(opts) > 8 and opts[8]  # also return x itself: its gradient (a skip path's) meets the data gradient here
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
+        slots_ok = bool(int(want_stats) & STATS_SLOTTED)   # the caller adds up a [slots][G][2][C] table (nn_ops -> bn.bn_act)
+        want_stats = int(want_stats) & 3
         groups = int(want_stats)                 # 0: none, 1: [2][C], 2: [2][2][C] (first / second half of the batch)
-        stats = zeropool.zeros((2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0]), x.device) if groups else None
         # bias + ReLU (PoseNet's decoder, model/posenet_single.py:160-164) ride in the Winograd epilogue; the backward then forms
         # dZ = dY * [Y > 0] and the bias gradient in one pre-activation pass (dvs_act_bwd), which needs Cout / 4 to divide 256
         wino_tail = (bias is None and act is None) or (act == "relu" and not groups and 256 % max(weight.shape[0] // 4, 1) == 0)
@@ -438,8 +444,14 @@ class _Conv2d(torch.autograd.Function):
                         and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2
                         * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
                         and wino_pays(x.shape[0], up2 * x.shape[2], up2 * x.shape[3], weight.shape[1], weight.shape[0]))
+        slots = STAT_SLOTS if (ctx.wino and groups and slots_ok and STAT_SLOTS > 1) else 1
+        if groups:
+            shape = (2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0])
+            stats = zeropool.zeros(((slots, groups) + shape[-2:]) if slots > 1 else shape, x.device)
+        else:
+            stats = None
         if ctx.wino:
-            y = conv3x3_wino(x, weight, stats, groups, bias=bias, relu=act == "relu")
+            y = conv3x3_wino(x, weight, stats, groups, bias=bias, relu=act == "relu", stat_slots=slots)
         elif ctx.wino_dec:
             y = conv3x3_wino_gen(x, x2, weight, bias, act, reflect=True)
         else:

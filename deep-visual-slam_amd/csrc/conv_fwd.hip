@@ -753,6 +753,13 @@ int dvs_act_bwd(const float* dy, const float* y, float* dz, size_t n, int act, f
     const size_t nvec = n / 4;
     size_t blocks = (nvec + 255) / 256;
     if (blocks > 512) blocks = 512;                      // grid-stride: few same-address atomics for the bias gradient
+    if (dbias) {
+        // every workgroup ends with one atomic per channel: 512 of them on a small tensor (PoseNet's decoder: 7 MB) serialise
+        // for ~45 us behind 6 us of streaming -- at least 32 grid-stride iterations per workgroup there
+        size_t few = nvec / (256 * 32);
+        few = few < 32 ? 32 : few;
+        if (blocks > few) blocks = few;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_CONV_DGRAD, st);       // counted with the data gradient (it serves both gradients)
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, dz, nvec, act, dbias, C);

@@ -43,6 +43,7 @@ struct WinoParams {
     int Ho, Wo, org;       // output size and patch origin: output tile (2ty, 2tx) reads input rows 2ty - org ... (1: 'same', 2: full)
     int act;               // epilogue activation code of conv_common.h (0 none, 1 ReLU, 2 ELU)
     const float* res;      // null, or a tensor of y's shape added to the convolution (before bias / activation)
+    int stat_mask, stat_stride;   // statistics slots: workgroup w adds into stats + (w & stat_mask) * stat_stride (0, 0: one copy)
 };
 
 // w [Cout][3][3][Cin] -> u [Cin][4][Cout][4] (flip = 0), or the data-gradient filter: u [Cout][4][Cin][4] from w rotated 180 degrees
@@ -452,12 +453,16 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         }
     }
     if (p.stats) {
+        // One workgroup per CU: a workgroup's last act is these atomics, and its CU stays occupied until they are acknowledged.  Thousands
+        // of workgroups adding to the SAME 2 x Cout addresses serialise in the L2 (~35 ns each: +120 us on a 140 us layer-1 launch at
+        // batch 24), so the workgroups spread over several copies of the table that the BatchNorm kernel adds up (dvs_bn_fwd_slots).
+        float* st = p.stats + (size_t)((int)blockIdx.x & p.stat_mask) * p.stat_stride;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const float a2 = ssum[g] + __shfl_xor(ssum[g], 32, 64), q2 = ssq[g] + __shfl_xor(ssq[g], 32, 64);
             if (h == 0 && co_ok && (a2 != 0.f || q2 != 0.f)) {
-                atomicAdd(p.stats + g * 2 * Cout + co, a2);
-                atomicAdd(p.stats + g * 2 * Cout + Cout + co, q2);
+                atomicAdd(st + g * 2 * Cout + co, a2);
+                atomicAdd(st + g * 2 * Cout + Cout + co, q2);
             }
         }
     }
@@ -729,13 +734,22 @@ int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroup
 
 int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
                          int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream) {
+    return dvs_conv3x3_wino_fwd_slots(x, u, bias, res, y, stats, stat_groups, 1, B, H, W, Cin, Cout, relu, as_dgrad, stream);
+}
+
+int dvs_conv3x3_wino_fwd_slots(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats,
+                               int stat_groups, int stat_slots, int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad,
+                               void* stream) {
     DVS_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_wino_fwd: bad argument");
+    DVS_REQUIRE(stat_slots >= 1 && stat_slots <= 64 && (stat_slots & (stat_slots - 1)) == 0,
+                "dvs_conv3x3_wino_fwd: stat_slots must be a power of two in [1, 64] (got %d)", stat_slots);
     DVS_REQUIRE(Cin % CIN_MULT == 0 && (Cout & 3) == 0, "dvs_conv3x3_wino_fwd: Cin %% 16 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
     DVS_REQUIRE(stat_groups >= 0 && stat_groups <= 2 && (stat_groups != 2 || (B & 1) == 0), "dvs_conv3x3_wino_fwd: stat_groups");
     DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
                 "dvs_conv3x3_wino_fwd: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     WinoParams p{x, u, bias, y, stats, B, H, W, Cin, Cout, 0, 0, relu, stat_groups == 2 ? B / 2 : 0x7fffffff,
-                 nullptr, Cin, 0, 0, H, W, 1, relu ? kActRelu : 0, res};
+                 nullptr, Cin, 0, 0, H, W, 1, relu ? kActRelu : 0, res, stat_slots - 1,
+                 stat_slots > 1 ? (stat_groups == 2 ? 2 : 1) * 2 * Cout : 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
     prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
@@ -758,7 +772,7 @@ int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const 
     const int Cin = C1 + C2;
     DVS_REQUIRE((double)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0 && (double)Cin * Cout * 64 < 2147483648.0,
                 "dvs_conv3x3_wino_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    WinoParams p{x, u, bias, y, nullptr, B, H, W, Cin, Cout, 0, 0, act == kActRelu, 0x7fffffff, x2, C1, upsample, reflect, Ho, Wo, org, act, nullptr};
+    WinoParams p{x, u, bias, y, nullptr, B, H, W, Cin, Cout, 0, 0, act == kActRelu, 0x7fffffff, x2, C1, upsample, reflect, Ho, Wo, org, act, nullptr, 0, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, st);      // flops of the direct convolution
     prof.work(2.0 * B * (as_dgrad ? H * W : Ho * Wo) * Cout * (double)Cin * 9);

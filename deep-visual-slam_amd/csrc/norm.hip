@@ -23,17 +23,23 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count,
                                    float* __restrict__ running_var, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, int C, long long* __restrict__ num_batches_tracked,
-                                   int groups) {
+                                   int groups, int slots) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    const size_t slot_stride = (size_t)groups * 2 * C;     // stats = [slots][G][2][C]: the copies are added up here
     if (c == 0 && num_batches_tracked) *num_batches_tracked += groups;
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_mean ? running_var[c] : 0.f;
     for (int grp = 0; grp < groups; ++grp) {
         const float* st = stats + (size_t)grp * 2 * C;
         const size_t o = (size_t)grp * 4 * C + c;
-        float mean = st[c] / count;
-        float var = fmaxf(st[C + c] / count - mean * mean, 0.f);     // biased, as used for normalisation
+        float s0 = st[c], s1 = st[C + c];
+        for (int k = 1; k < slots; ++k) {
+            s0 += st[k * slot_stride + c];
+            s1 += st[k * slot_stride + C + c];
+        }
+        float mean = s0 / count;
+        float var = fmaxf(s1 / count - mean * mean, 0.f);     // biased, as used for normalisation
         float invstd = rsqrtf(var + eps);
         scale[o] = g * invstd;
         shift[o] = b - mean * g * invstd;
@@ -96,7 +102,13 @@ struct BnFusedArgs {
     long long* nbt;          // or NULL
     float* fin;              // [G][4][C] out: scale, shift, mean, invstd
     float count, momentum, eps;
+    int slots;               // stats = [slots][G][2][C] (copies the producing kernel spread its atomics over), added up on load
 };
+__device__ __forceinline__ f32x4 load_stat(const float* __restrict__ st, int slots, size_t slot_stride) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(st);
+    for (int k = 1; k < slots; ++k) v += *reinterpret_cast<const f32x4*>(st + k * slot_stride);
+    return v;
+}
 __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const float* __restrict__ y, const float* __restrict__ r,
                                                           const float* __restrict__ rsc, const float* __restrict__ rsh,
                                                           float* __restrict__ z, size_t n4, int C, int relu, int groups) {
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
         for (int q = 0; q < groups; ++q) {
             const float* st = a.stats + (size_t)q * 2 * C;
             float* out = a.fin + (size_t)q * 4 * C;
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + c), s1 = *reinterpret_cast<const f32x4*>(st + C + c);
+            const f32x4 s0 = load_stat(st + c, a.slots, (size_t)groups * 2 * C), s1 = load_stat(st + C + c, a.slots, (size_t)groups * 2 * C);
             f32x4 sc, sh, mu, is;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
     f32x4 s, t;
     {
         const float* st = a.stats + (size_t)grp * 2 * C;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + c), s1 = *reinterpret_cast<const f32x4*>(st + C + c);
+        const f32x4 s0 = load_stat(st + c, a.slots, (size_t)groups * 2 * C), s1 = load_stat(st + C + c, a.slots, (size_t)groups * 2 * C);
         const f32x4 g = a.gamma ? *reinterpret_cast<const f32x4*>(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
         const f32x4 b = a.beta ? *reinterpret_cast<const f32x4*>(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -536,11 +548,19 @@ extern "C" {
 int dvs_bn_finalize(const float* stats, double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
                     float* invstd, int C, long long* num_batches_tracked, int groups, void* stream) {
-    DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1 && groups >= 1, "dvs_bn_finalize: bad argument");
+    return dvs_bn_finalize_slots(stats, 1, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C,
+                                 num_batches_tracked, groups, stream);
+}
+
+int dvs_bn_finalize_slots(const float* stats, int stat_slots, double count, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                          float* invstd, int C, long long* num_batches_tracked, int groups, void* stream) {
+    DVS_REQUIRE(stats && scale && shift && mean && invstd && C > 0 && count >= 1 && groups >= 1 && stat_slots >= 1,
+                "dvs_bn_finalize: bad argument");
     DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_finalize: running stats come together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), stats,
                        (float)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, C,
-                       num_batches_tracked, groups);
+                       num_batches_tracked, groups, stat_slots);
     return dvs::check_launch("dvs_bn_finalize");
 }
 
@@ -548,12 +568,21 @@ int dvs_bn_fwd(const float* y, const float* stats, double count, const float* ga
                float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
                float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
                int C, int relu, int groups, void* stream) {
-    DVS_REQUIRE(y && stats && fin && z && M > 0 && C > 0 && (C & 3) == 0 && count >= 1 && groups >= 1, "dvs_bn_fwd: bad argument");
+    return dvs_bn_fwd_slots(y, stats, 1, count, gamma, beta, running_mean, running_var, momentum, eps, num_batches_tracked, fin,
+                            residual, res_scale, res_shift, z, M, C, relu, groups, stream);
+}
+
+int dvs_bn_fwd_slots(const float* y, const float* stats, int stat_slots, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
+                     float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
+                     int C, int relu, int groups, void* stream) {
+    DVS_REQUIRE(y && stats && fin && z && M > 0 && C > 0 && (C & 3) == 0 && count >= 1 && groups >= 1 && stat_slots >= 1,
+                "dvs_bn_fwd: bad argument");
     DVS_REQUIRE(C / 4 <= NT && (NT % (C / 4)) == 0, "dvs_bn_fwd: C/4 must divide 256 (C=%d)", C);
     DVS_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dvs_bn_fwd: running stats come together");
     DVS_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (!res_scale || residual),
                 "dvs_bn_fwd: residual affine needs residual, scale and shift");
-    BnFusedArgs a{stats, gamma, beta, running_mean, running_var, num_batches_tracked, fin, (float)count, momentum, eps};
+    BnFusedArgs a{stats, gamma, beta, running_mean, running_var, num_batches_tracked, fin, (float)count, momentum, eps, stat_slots};
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_FWD, st);

@@ -143,7 +143,7 @@ def conv_bn_relu_with_identity(x, weight, bn, stride=1, padding=0):
         return conv_bn_act(x, weight, bn, stride, padding, relu=True), x
     _require_gpu(x, "conv_bn_act")
     G = _batch_groups
-    y, st, xa = _conv.conv2d(x, weight, None, stride, padding, want_stats=G, passthrough=True)
+    y, st, xa = _conv.conv2d(x, weight, None, stride, padding, want_stats=G | _conv.STATS_SLOTTED, passthrough=True)
     return _bn.bn_act(y, bn, st, True, groups=G), xa
 
 
@@ -196,9 +196,9 @@ def conv_bn_act(x, weight, bn, stride=1, padding=0, relu=True, residual=None, re
             yd = _conv.conv2d(residual, res[0], None, res[2], 0)
             return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=_bn.channel_stats(yd.detach(), G), groups=G)
         return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
-    y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G)
+    y, st = _conv.conv2d(x, weight, None, stride, padding, planar_norm=planar_norm, want_stats=G | _conv.STATS_SLOTTED)
     if res is not None:
-        yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G)
+        yd, std = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G | _conv.STATS_SLOTTED)
         return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G)
     return _bn.bn_act(y, bn, st, relu, residual=residual, groups=G)
 
@@ -211,8 +211,8 @@ def _conv_bn_act_ds_passthrough(x, weight, bn, stride, padding, relu, residual, 
             or not _bn.supported_c(weight.shape[0], bn) or not _bn.supported_c(res[0].shape[0], res[1])):
         return conv_bn_act(x, weight, bn, stride, padding, relu, residual, res), residual
     G = _batch_groups
-    y, st = _conv.conv2d(x, weight, None, stride, padding, want_stats=G)
-    yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G, passthrough=True)
+    y, st = _conv.conv2d(x, weight, None, stride, padding, want_stats=G | _conv.STATS_SLOTTED)
+    yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G | _conv.STATS_SLOTTED, passthrough=True)
     return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G), ra
 
 
@@ -231,7 +231,7 @@ def stem_conv_bn_relu_pool(x, weight, bn, planar_norm, need_z=True):
         p, z = max_pool_3x3_s2(z, passthrough=True)
         return z, p
     G = _batch_groups
-    y, st = _conv.conv2d(x, weight, None, 2, 3, planar_norm=planar_norm, want_stats=G)
+    y, st = _conv.conv2d(x, weight, None, 2, 3, planar_norm=planar_norm, want_stats=G | _conv.STATS_SLOTTED)
     return _bn.bn_relu_pool(y, bn, st, groups=G, need_z=need_z)
 
 

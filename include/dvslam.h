@@ -162,6 +162,13 @@ int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, in
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
                          int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);
+/*   dvs_conv3x3_wino_fwd_slots (ABI 5): the statistics go to `stat_slots` copies of the table, stats = [stat_slots][G][2][Cout]
+ *   (power of two <= 64, zero-filled by the caller): workgroup w adds into copy w % stat_slots, and dvs_bn_fwd_slots /
+ *   dvs_bn_finalize_slots add the copies up.  The kernel runs one workgroup per CU whose last act is these atomics; with one
+ *   copy, thousands of same-address atomics serialise in the L2 and each workgroup's CU waits for them. */
+int dvs_conv3x3_wino_fwd_slots(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats,
+                               int stat_groups, int stat_slots, int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad,
+                               void* stream);
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
 /*   dvs_conv2d_pack_wt_batch: the same transpose for many weights in one launch.  `table` (device memory) = n_entries
  *   records { const float* w; float* wt; int Cout, Cin, taps, wg_begin; } (32 bytes each), wg_begin = number of
@@ -255,6 +262,14 @@ int dvs_bn_fwd(const float* y, const float* stats, double count, const float* ga
                float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
                float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
                int C, int relu, int groups, void* stream);
+/* the same with `stats` = [stat_slots][G][2][C]: copies that are added up on load (dvs_conv3x3_wino_fwd_slots) */
+int dvs_bn_fwd_slots(const float* y, const float* stats, int stat_slots, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, long long* num_batches_tracked,
+                     float* fin, const float* residual, const float* res_scale, const float* res_shift, float* z, size_t M,
+                     int C, int relu, int groups, void* stream);
+int dvs_bn_finalize_slots(const float* stats, int stat_slots, double count, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, float* scale, float* shift, float* mean,
+                          float* invstd, int C, long long* num_batches_tracked, int groups, void* stream);
 int dvs_bn_apply_fwd(const float* y, const float* scale, const float* shift, const float* residual,
                      const float* res_scale, const float* res_shift, float* z, size_t M, int C, int relu, int groups,
                      void* stream);

@@ -298,3 +298,27 @@ def test_bias_relu_layer_autograd_matches_torch(B, c, h, w):
         assert _rel(x.grad, x64.grad) < TOL and _rel(wt.grad, w64.grad) < 2e-5 and _rel(b.grad, b64.grad) < 2e-5
     else:
         assert _rel(x.grad, x64.grad) < 1e-3 and _rel(wt.grad, w64.grad) < 1e-3 and _rel(b.grad, b64.grad) < 1e-3
+
+
+@pytest.mark.parametrize("B,c,h,w,groups", [(4, 64, 60, 80, 1), (4, 64, 60, 80, 2), (2, 128, 13, 27, 1)])
+def test_statistics_spread_over_slots(B, c, h, w, groups):
+    """dvs_conv3x3_wino_fwd_slots: the workgroups add their BatchNorm statistics into 16 copies of the table (one workgroup per CU
+    ends with these atomics; on ONE copy they serialise); the copies add up to the sums, and bn.bn_act consumes the copies."""
+    import torch.nn as nn
+    from deep_visual_slam_amd import bn as DB, conv as DC
+    x, wt = _mk(B, c, c, h, w, seed=9)
+    y64 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    st = torch.zeros(16, groups, 2, c, device="cuda")
+    y = DC.conv3x3_wino(x, wt, st, groups, stat_slots=16)
+    assert _rel(y, y64) < TOL
+    assert int((st.abs().sum((1, 2, 3)) > 0).sum()) > 1            # more than one copy was used
+    parts = y64.chunk(groups, 0)
+    ref = torch.stack([torch.stack([p.sum((0, 2, 3)), (p * p).sum((0, 2, 3))]) for p in parts])
+    tot = st.double().sum(0)
+    assert float((tot - ref).abs().max() / ref.abs().max()) < 2e-5
+    # BatchNorm forward from the slotted table == from the summed table
+    m1, m2 = nn.BatchNorm2d(c).cuda().train(), nn.BatchNorm2d(c).cuda().train()
+    z1 = DB.bn_act(y, m1, st, True, groups=groups)
+    z2 = DB.bn_act(y, m2, st.sum(0) if groups > 1 else st.sum(0)[0], True, groups=groups)
+    assert float((z1 - z2).abs().max()) < 1e-5
+    assert torch.allclose(m1.running_var, m2.running_var, rtol=1e-5, atol=1e-7)
