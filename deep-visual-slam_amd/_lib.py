@@ -53,7 +53,8 @@ class ConvDesc(C.Structure):
 
 class ConvFusion(C.Structure):
     _fields_ = [("x2", _vp), ("C1", C.c_int), ("in_scale", _vp), ("in_shift", _vp), ("in_relu", C.c_int),
-                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp), ("stat_groups", C.c_int), ("residual", _vp)]
+                ("nchw_planar", C.c_int), ("act", C.c_int), ("stats", _vp), ("stat_groups", C.c_int), ("residual", _vp),
+                ("stat_slots", C.c_int)]
 
 
 _SIGNATURES = {
@@ -64,7 +65,7 @@ _SIGNATURES = {
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),
-    "dvs_conv3x3_wino_fwd_slots": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp]),
+    "dvs_conv3x3_wino_fwd_slots": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 9 + [_vp]),
     "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv2d_pack_wt_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_reflect_fold": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -70,7 +70,7 @@ def _geometry(x, w_shape, x2, nchw_planar):
     return x, x2, B, Cin, H, W
 
 
-def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None, stat_groups=1, residual=None):
+def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=None, stat_groups=1, residual=None, stat_slots=1):
     f = ConvFusion()
     if residual is not None:
         f.residual = residual.data_ptr()      # NHWC memory, checked by the caller
@@ -85,6 +85,7 @@ def _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act=None, stats=Non
     if stats is not None:
         f.stats = ptr(stats)
         f.stat_groups = int(stat_groups)
+        f.stat_slots = int(stat_slots)
     return f
 
 
@@ -94,7 +95,7 @@ def _pack_planar_weight(weight):
 
 
 def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=None, x2=None, in_scale=None,
-                   in_shift=None, in_relu=False, nchw_planar=False, stats=None, stat_groups=1, residual=None):
+                   in_shift=None, in_relu=False, nchw_planar=False, stats=None, stat_groups=1, residual=None, stat_slots=1):
     """Raw forward launch (no autograd).  x: logical [B,Cin,H,W] (NHWC memory, or planar NCHW when
     nchw_planar); with x2 the logical input is cat([upsample2x(x), x2], 1); residual (inference only): a tensor of
     the output's shape added before the activation."""
@@ -109,7 +110,7 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
         residual = _nhwc(residual)
         if tuple(residual.shape) != tuple(y.shape):
             raise _lib.DvsError("conv2d_forward: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats, stat_groups, residual)
+    f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar, act, stats, stat_groups, residual, stat_slots)
     check(_lib.lib().dvs_conv2d_fwd(x.data_ptr(), w.data_ptr(), ptr(bias), y.data_ptr(), C.byref(d), C.byref(f),
                                     _lib.stream()), "dvs_conv2d_fwd")
     return y
@@ -416,6 +417,7 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
     return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
+_DIRECT_SLOTS = os.environ.get("DVS_DIRECT_STAT_SLOTS", "1") != "0"    # also for the implicit-GEMM kernels' statistics epilogue
 STATS_SLOTTED = 4      # flag in conv2d(want_stats=G | STATS_SLOTTED): the statistics may come back as [slots][G][2][C]
 _PREACT = os.environ.get("DVS_CONV_PREACT", "1") != "0"
 _PADDED = os.environ.get("DVS_CONV_PADDED_DGRAD", "1") != "0"
@@ -444,7 +446,8 @@ class _Conv2d(torch.autograd.Function):
                         and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2
                         * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
                         and wino_pays(x.shape[0], up2 * x.shape[2], up2 * x.shape[3], weight.shape[1], weight.shape[0]))
-        slots = STAT_SLOTS if (ctx.wino and groups and slots_ok and STAT_SLOTS > 1) else 1
+        # the statistics epilogues end with same-address atomics: spread over STAT_SLOTS copies where the consumer adds them up
+        slots = STAT_SLOTS if (groups and slots_ok and STAT_SLOTS > 1 and not planar and (ctx.wino or _DIRECT_SLOTS)) else 1
         if groups:
             shape = (2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0])
             stats = zeropool.zeros(((slots, groups) + shape[-2:]) if slots > 1 else shape, x.device)
@@ -456,7 +459,7 @@ class _Conv2d(torch.autograd.Function):
             y = conv3x3_wino_gen(x, x2, weight, bias, act, reflect=True)
         else:
             y = conv2d_forward(x, weight, bias, stride, pad, reflect, act, x2=x2, in_scale=scale, in_shift=shift,
-                               nchw_planar=planar, stats=stats, stat_groups=max(groups, 1))
+                               nchw_planar=planar, stats=stats, stat_groups=max(groups, 1), stat_slots=slots)
         ctx.opts = opts[:7]
         ctx.x_shape = tuple(x.shape)
         ctx.has_bias = bias is not None

@@ -32,6 +32,7 @@ struct FwdParams {
     int dbg_nobarrier;   // timing experiment only (DVS_CONV_DEBUG_NOBARRIER=1): skip the K-loop barriers -> wrong results
     const float* zero_page;   // 16 bytes of zeros: what the LDS-DMA kernel fetches for padding / tail lanes
     const float* res;         // [B,Ho,Wo,Cout] added before the activation (inference BasicBlock tail), or NULL
+    int stat_mask, stat_stride;   // statistics copies: output tile t adds into stats + (t & stat_mask) * stat_stride (0, 0: one table)
     int work_m;               // rows to count as algorithmic work in the profile (0 = all M rows): the padded-domain data
                               // gradient computes a border of rows that the unpadded problem does not have
     int ksplit;               // > 1: split-K launch of the LDS-DMA kernel -- raw partial sums are added into a zero-filled y
@@ -141,6 +142,7 @@ __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const Con
             }
         }
         if (STATS) {
+            float* st = p.stats + (size_t)((m0 / bm) & p.stat_mask) * p.stat_stride;
             if (STATS == 1 && tile_second) {
                 ssum1 = ssum;
                 ssq1 = ssq;
@@ -150,16 +152,16 @@ __device__ __forceinline__ void conv_epilogue_body(const FwdParams& p, const Con
                 ssum += __shfl_xor(ssum, 32, 64);
                 ssq += __shfl_xor(ssq, 32, 64);
                 if (lh == 0 && n_ok) {
-                    atomicAdd(p.stats + n, ssum);
-                    atomicAdd(p.stats + s.Cout + n, ssq);
+                    atomicAdd(st + n, ssum);
+                    atomicAdd(st + s.Cout + n, ssq);
                 }
             }
             if (STATS == 2 || tile_second) {
                 ssum1 += __shfl_xor(ssum1, 32, 64);
                 ssq1 += __shfl_xor(ssq1, 32, 64);
                 if (lh == 0 && n_ok) {
-                    atomicAdd(p.stats + 2 * s.Cout + n, ssum1);
-                    atomicAdd(p.stats + 3 * s.Cout + n, ssq1);
+                    atomicAdd(st + 2 * s.Cout + n, ssum1);
+                    atomicAdd(st + 3 * s.Cout + n, ssq1);
                 }
             }
         }
@@ -855,6 +857,12 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
         DVS_REQUIRE(f->stat_groups >= 0 && f->stat_groups <= 2 && (f->stat_groups != 2 || (d->B % 2) == 0),
                     "dvs_conv2d_fwd: stat_groups is 0, 1 or 2 (2 needs an even batch)");
         p.stat_split = (f->stat_groups == 2) ? (d->B / 2) * s.Ho * s.Wo : 0x7fffffff;
+        if (f->stats && f->stat_slots > 1) {
+            DVS_REQUIRE(f->stat_slots <= 64 && (f->stat_slots & (f->stat_slots - 1)) == 0 && !f->nchw_planar,
+                        "dvs_conv2d_fwd: stat_slots must be a power of two <= 64 (NHWC input only)");
+            p.stat_mask = f->stat_slots - 1;
+            p.stat_stride = (f->stat_groups == 2 ? 2 : 1) * 2 * d->Cout;
+        }
         // C1 == Cin: upsample only (x2 is never read); otherwise the concat boundary must not split a 32-k stage
         DVS_REQUIRE(!(f->x2) || (f->C1 > 0 && (d->H & 1) == 0 && (d->W & 1) == 0 &&
                                  ((f->C1 == d->Cin && (f->C1 & 3) == 0) || (f->C1 < d->Cin && (f->C1 % BK) == 0))),

@@ -33,8 +33,21 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, float count,
     for (int grp = 0; grp < groups; ++grp) {
         const float* st = stats + (size_t)grp * 2 * C;
         const size_t o = (size_t)grp * 4 * C + c;
-        float s0 = st[c], s1 = st[C + c];
-        for (int k = 1; k < slots; ++k) {
+        float a0[16], a1[16];                               // every copy's load in flight before the first add
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const size_t o = (k < slots ? k : 0) * slot_stride;
+            a0[k] = st[o + c];
+            a1[k] = st[o + C + c];
+        }
+        float s0 = a0[0], s1 = a1[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+            if (k < slots) {
+                s0 += a0[k];
+                s1 += a1[k];
+            }
+        for (int k = 16; k < slots; ++k) {
             s0 += st[k * slot_stride + c];
             s1 += st[k * slot_stride + C + c];
         }
@@ -104,10 +117,34 @@ struct BnFusedArgs {
     float count, momentum, eps;
     int slots;               // stats = [slots][G][2][C] (copies the producing kernel spread its atomics over), added up on load
 };
-__device__ __forceinline__ f32x4 load_stat(const float* __restrict__ st, int slots, size_t slot_stride) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(st);
-    for (int k = 1; k < slots; ++k) v += *reinterpret_cast<const f32x4*>(st + k * slot_stride);
-    return v;
+// Sums of the copies of one table entry pair (sum, sum of squares; C floats apart).  One copy: two plain loads.  Several: all loads
+// are issued before the first add (a loop of load-then-add waits for every load in turn: 16 dependent L2 round trips, ~11 us, at
+// the head of every workgroup of the BatchNorm kernel).
+__device__ __forceinline__ void load_stat2(const float* __restrict__ st, int C, int slots, size_t slot_stride, f32x4& s0, f32x4& s1) {
+    if (slots <= 1) {
+        s0 = *reinterpret_cast<const f32x4*>(st);
+        s1 = *reinterpret_cast<const f32x4*>(st + C);
+        return;
+    }
+    f32x4 a[16], b[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float* q = st + (k < slots ? k : 0) * slot_stride;
+        a[k] = *reinterpret_cast<const f32x4*>(q);
+        b[k] = *reinterpret_cast<const f32x4*>(q + C);
+    }
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (k < slots) {
+            a[0] += a[k];
+            b[0] += b[k];
+        }
+    for (int k = 16; k < slots; ++k) {
+        a[0] += *reinterpret_cast<const f32x4*>(st + k * slot_stride);
+        b[0] += *reinterpret_cast<const f32x4*>(st + k * slot_stride + C);
+    }
+    s0 = a[0];
+    s1 = b[0];
 }
 __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const float* __restrict__ y, const float* __restrict__ r,
                                                           const float* __restrict__ rsc, const float* __restrict__ rsh,
@@ -126,7 +163,8 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
         for (int q = 0; q < groups; ++q) {
             const float* st = a.stats + (size_t)q * 2 * C;
             float* out = a.fin + (size_t)q * 4 * C;
-            const f32x4 s0 = load_stat(st + c, a.slots, (size_t)groups * 2 * C), s1 = load_stat(st + C + c, a.slots, (size_t)groups * 2 * C);
+            f32x4 s0, s1;
+            load_stat2(st + c, C, a.slots, (size_t)groups * 2 * C, s0, s1);
             f32x4 sc, sh, mu, is;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -149,11 +187,14 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
             *reinterpret_cast<f32x4*>(a.running_var + c) = rv;
         }
     }
-    // my channels' folded scale / shift for this group
+    // my channels' folded scale / shift for this group: derived once per workgroup by the first C/4 threads (with a slotted table
+    // every thread adding up the copies itself cost +0.5 ms per step), read back from LDS by everyone
+    __shared__ f32x4 s_sc[NT], s_sh[NT];
     f32x4 s, t;
-    {
+    if (threadIdx.x < C / 4) {
         const float* st = a.stats + (size_t)grp * 2 * C;
-        const f32x4 s0 = load_stat(st + c, a.slots, (size_t)groups * 2 * C), s1 = load_stat(st + C + c, a.slots, (size_t)groups * 2 * C);
+        f32x4 s0, s1;
+        load_stat2(st + c, C, a.slots, (size_t)groups * 2 * C, s0, s1);
         const f32x4 g = a.gamma ? *reinterpret_cast<const f32x4*>(a.gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
         const f32x4 b = a.beta ? *reinterpret_cast<const f32x4*>(a.beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -164,7 +205,12 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
             s[j] = g[j] * is;
             t[j] = b[j] - mu * g[j] * is;
         }
+        s_sc[threadIdx.x] = s;                 // thread i < C/4 holds channels 4i .. 4i+3 (c = 4i)
+        s_sh[threadIdx.x] = t;
     }
+    __syncthreads();
+    s = s_sc[c / 4];
+    t = s_sh[c / 4];
     f32x4 s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
     if (rsc) {
         s2 = *reinterpret_cast<const f32x4*>(rsc + (size_t)grp * 4 * C + c);

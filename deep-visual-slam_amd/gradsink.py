@@ -72,6 +72,21 @@ def enable_side_streams(on):
     _enabled = bool(on)
 
 
+def _priority(kind):
+    """HIP stream priority for the weight-gradient side streams (DVS_SIDE_PRIORITY=low|normal) and the PoseNet stream
+    (DVS_POSE_PRIORITY=high|normal): the data-gradient chains are the critical path of the step, the weight gradients only have to be
+    done by the optimiser step -- with a lower queue priority their workgroups take the CUs the chains leave."""
+    want = os.environ.get("DVS_SIDE_PRIORITY" if kind == "side" else "DVS_POSE_PRIORITY", _PRIORITY_DEFAULT[kind])
+    try:
+        least, greatest = torch.cuda.Stream.priority_range()
+    except Exception:
+        return 0
+    return {"low": least, "high": greatest}.get(want, 0)
+
+
+_PRIORITY_DEFAULT = {"side": "normal", "pose": "normal"}
+
+
 def side_stream():
     """Side stream paired with the current stream, or None when disabled."""
     if not _enabled:
@@ -85,7 +100,7 @@ def side_stream():
             for (dev, _), (_, side) in _side.items():
                 if dev == cur.device_index:
                     shared = side
-        pair = _side[key] = (cur, shared if shared is not None else torch.cuda.Stream(device=cur.device))
+        pair = _side[key] = (cur, shared if shared is not None else torch.cuda.Stream(device=cur.device, priority=_priority("side")))
     return pair[1]
 
 

@@ -105,7 +105,7 @@ class MonodepthTrainer:
         # The two PoseNet passes stay in order on that one stream (they update the same BatchNorm running statistics).
         self.pose_pairs_batched = bool(tr.get("pose_pairs_batched", os.environ.get("DVS_POSE_BATCHED", "1") != "0"))
         use_stream = tr.get("pose_stream", os.environ.get("DVS_POSE_STREAM", "1") != "0")
-        self.pose_stream = (torch.cuda.Stream(device=self.device)
+        self.pose_stream = (torch.cuda.Stream(device=self.device, priority=gradsink._priority("pose"))
                             if use_stream and torch.device(self.device).type == "cuda" else None)
         ops.chain_aux_stream = self.pose_stream          # loss-chain backward by scale (DVS_CHAIN_SPLIT=1) runs its coarse scales there
         self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]

@@ -115,6 +115,10 @@ typedef struct {
     const float* residual;  /* non-NULL: [B,Ho,Wo,Cout] added before the activation: y = act(conv + bias + residual) --
                                the BasicBlock tail relu(bn2(conv2(.)) + identity) with an eval-mode BatchNorm folded
                                into w / bias (inference path of model/resnet_encoder.py:100-111) */
+    int stat_slots;         /* (ABI 5) 0 / 1: one table; a power of two <= 64: stats is [stat_slots][G][2][Cout] and output tile t
+                               adds into copy t % stat_slots -- a 1x1 downsample convolution is all epilogue, and ~900 tiles
+                               adding to the same 2 x Cout addresses serialise in the L2; dvs_bn_fwd_slots adds the copies up.
+                               Not for the planar (conv1) input. */
 } dvs_conv_fusion;
 
 /* y [B,Ho,Wo,Cout] = act(conv(x, w) + bias); `f` may be NULL (no fusion). */

@@ -26,6 +26,19 @@ def test_header_and_binding_agree(built):
     assert header_symbols() == built.exported_symbols()
 
 
+def test_binding_arity_matches_the_header(built):
+    """Every ctypes signature passes exactly as many arguments as the prototype in include/dvslam.h declares (a miscounted
+    binding only fails at its first call, on the GPU box)."""
+    src = open(os.path.join(ROOT, "include", "dvslam.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name, (_, args) in built._SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
 def test_library_exports_every_symbol(built):
     l = built.lib()
     for name in header_symbols():
