@@ -81,6 +81,8 @@ _SIGNATURES = {
     "dvs_maxpool3x3s2_bwd_res": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_upsample2x_fwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_upsample2x_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_bn_bwd_slot_floats": (C.c_int, [C.c_int, C.c_int]),
+    "dvs_bn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_bn_relu_maxpool_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_bn_relu_maxpool_bwd": (C.c_int, [_vp] * 9 + [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp]),
     "dvs_bn_finalize": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, _vp]),

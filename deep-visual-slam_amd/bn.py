@@ -11,6 +11,11 @@ import torch
 from . import _lib, gradsink, zeropool
 from ._lib import check, ptr
 
+# DVS_BN_BWD_FUSED=1: reduce + apply without the partial-row sum kernel (dvs_bn_bwd).  Measured SLOWER over the step (26.96 -> 27.07 ms):
+# the deep layers' tables are large next to their data (C = 512: 450 workgroups x 1 024 float atomics, then 128 KB of copies read by
+# every workgroup of the apply pass: +12 us on each 11 us kernel), only the 64-channel layers break even -- so it stays off; the stem
+# tail (C = 64, 10^6 rows) always uses the slot table.
+_BWD_FUSED = os.environ.get("DVS_BN_BWD_FUSED", "0") == "1"
 _YMASK = os.environ.get("DVS_BN_YMASK", "1") != "0"     # ReLU mask of residual-free BatchNorms recomputed from y in the backward
 
 CL = torch.channels_last
@@ -85,8 +90,13 @@ class _BNAct(torch.autograd.Function):
         du = torch.empty_like(y) if need_du else dz
         dy = torch.empty_like(y)
         pooled = gamma.is_leaf and gamma.grad is not None
-        sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
-        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
+        fused = not _lib.deterministic() and _BWD_FUSED      # dvs_bn_bwd: no partial-row sum kernel between the two passes
+        if fused:
+            sums = torch.empty((G, 2, C), device=y.device, dtype=torch.float32)
+            ws = zeropool.zeros((l.dvs_bn_bwd_slot_floats(C, G),), y.device)
+        else:
+            sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
+            ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
         g_par, b_par, rg_par, rb_par = ctx.affine
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
@@ -97,10 +107,21 @@ class _BNAct(torch.autograd.Function):
         if residual is not None:
             d_res = torch.empty_like(residual) if ds_res else du
         if ds_res:
-            rsums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
+            rsums = (torch.empty((G, 2, C), device=y.device, dtype=torch.float32) if fused
+                     else zeropool.zeros((G, 2, C), y.device, pooled=pooled))
             rgs, rbs = gradsink.target(rg_par), gradsink.target(rb_par)
             rsunk = rgs is not None and rbs is not None
-        if ctx.ymask:
+        if fused:
+            check(l.dvs_bn_bwd(dz.data_ptr(), z.data_ptr() if (ctx.relu and not ctx.ymask) else None, y.data_ptr(), fin.data_ptr(),
+                               int(ctx.ymask), ptr(gamma), du.data_ptr() if need_du else None, dy.data_ptr(), ws.data_ptr(),
+                               None if sunk else sums.data_ptr(), M, C, ptr(gs) if sunk else None, ptr(bs) if sunk else None, G, st),
+                  "dvs_bn_bwd")
+            if ds_res:
+                ws2 = zeropool.zeros((l.dvs_bn_bwd_slot_floats(C, G),), y.device)
+                check(l.dvs_bn_bwd(du.data_ptr(), None, residual.data_ptr(), res_fin.data_ptr(), 0, ptr(res_gamma), None,
+                                   d_res.data_ptr(), ws2.data_ptr(), None if rsunk else rsums.data_ptr(), M, C,
+                                   ptr(rgs) if rsunk else None, ptr(rbs) if rsunk else None, G, st), "dvs_bn_bwd")
+        elif ctx.ymask:
             check(l.dvs_bn_bwd_reduce_ymask(dz.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
                                             fin[0, 0].data_ptr(), fin[0, 1].data_ptr(), sums.data_ptr(), ptr(ws), M, C, G, st),
                   "dvs_bn_bwd_reduce_ymask")
@@ -114,7 +135,7 @@ class _BNAct(torch.autograd.Function):
             check(l.dvs_bn_bwd_apply(du.data_ptr(), y.data_ptr(), fin[0, 2].data_ptr(), fin[0, 3].data_ptr(),
                                      ptr(gamma), sums.data_ptr(), dy.data_ptr(), M, C, ptr(gs) if sunk else None,
                                      ptr(bs) if sunk else None, G, st), "dvs_bn_bwd_apply")
-        if ds_res:
+        if ds_res and not fused:
             check(l.dvs_bn_bwd_reduce(du.data_ptr(), None, residual.data_ptr(), res_fin[0, 2].data_ptr(),
                                       res_fin[0, 3].data_ptr(), None, rsums.data_ptr(), ptr(ws), M, C, G, st),
                   "dvs_bn_bwd_reduce")
@@ -165,9 +186,8 @@ class _BNReluPool(torch.autograd.Function):
         if dz is not None:
             dz = dz if dz.is_contiguous(memory_format=CL) else dz.contiguous(memory_format=CL)
         dy = torch.empty_like(y)
-        pooled = gamma.is_leaf and gamma.grad is not None
-        sums = zeropool.zeros((G, 2, C), y.device, pooled=pooled)
-        ws = torch.empty(l.dvs_bn_bwd_workspace(M, C, G) // 4, device=y.device, dtype=torch.float32)
+        sums = torch.empty((G, 2, C), device=y.device, dtype=torch.float32)
+        ws = zeropool.zeros((l.dvs_bn_bwd_slot_floats(C, G),), y.device)      # the slot table of dvs_bn_bwd
         g_par, b_par = ctx.affine
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None

@@ -239,13 +239,55 @@ __global__ __launch_bounds__(NT) void bn_fwd_fused_kernel(BnFusedArgs a, const f
     }
 }
 
+// One-launch-less BatchNorm backward (dvs_bn_bwd): instead of one partial row per workgroup and a second kernel that sums the rows,
+// workgroup w adds its partial sums into copy w % BWD_SLOTS of a zero-filled [G][BWD_SLOTS][2][C] table (2048 workgroups -> 64
+// same-address atomics per copy, issued while seven other workgroups of the CU stream), and every workgroup of the apply kernel adds
+// the copies up at its head (C/4 threads, all loads of a round in flight together) -- the 40 sum kernels of a step (6 us + a launch
+// gap each, inside the dependency chains) are gone.  The deterministic mode keeps the ordered two-kernel sum.
+constexpr int BWD_SLOTS = 32;
+
+__device__ __forceinline__ void slot_add(float* __restrict__ slots, int grp, int wg, int C, int c, const f32x4& a, const f32x4& b) {
+    float* row = slots + ((size_t)grp * BWD_SLOTS + (wg % BWD_SLOTS)) * 2 * C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        atomicAdd(row + c + j, a[j]);
+        atomicAdd(row + C + c + j, b[j]);
+    }
+}
+
+// Totals of group `grp` for the channels 4 * tid .. of the first C/4 threads -> LDS tot[2][C]; the caller synchronises.
+__device__ __forceinline__ void slot_totals(const float* __restrict__ slots, int grp, int C, float* __restrict__ tot) {
+    if ((int)threadIdx.x < C / 4) {
+        const int c = threadIdx.x * 4;
+        const float* base = slots + (size_t)grp * BWD_SLOTS * 2 * C;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < BWD_SLOTS / 16; ++r) {
+            f32x4 a[16], b[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                a[k] = *reinterpret_cast<const f32x4*>(base + (size_t)(r * 16 + k) * 2 * C + c);
+                b[k] = *reinterpret_cast<const f32x4*>(base + (size_t)(r * 16 + k) * 2 * C + C + c);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                s0 += a[k];
+                s1 += b[k];
+            }
+        }
+        *reinterpret_cast<f32x4*>(tot + c) = s0;
+        *reinterpret_cast<f32x4*>(tot + C + c) = s1;
+    }
+}
+
 // Column reduction over pixels.  A workgroup owns rows [blockIdx.x * rows_per_block, ...): lane -> (row lane,
 // 4-channel vector); sums[0][c] += sum du, sums[1][c] += sum du * xhat; optionally writes du.
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ z,
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ du_out,
-                                                           float* __restrict__ sums, int M, int C, int rows_per_block) {
+                                                           float* __restrict__ sums, int M, int C, int rows_per_block,
+                                                           float* __restrict__ slots) {
     extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
     {   // blockIdx.y = group: M rows each; the partial rows of group g follow those of group g - 1
         const size_t go = (size_t)blockIdx.y * M * C, po = (size_t)blockIdx.y * 4 * C;
@@ -319,6 +361,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const float* __restri
         }
         // one partial row per workgroup (same-address float atomics from ~2000 workgroups serialise at
         // ~85 ns each -- measured 6x the streaming time of this kernel -- so a second small kernel sums them)
+        if (slots) {       // ... or the workgroups spread over BWD_SLOTS copies of the table, which the apply kernel adds up (dvs_bn_bwd)
+            slot_add(slots, blockIdx.y, blockIdx.x, C, c, a, b);
+            return;
+        }
         float* row = sums + (size_t)blockIdx.x * 2 * C;
         *reinterpret_cast<f32x4*>(row + c) = a;
         *reinterpret_cast<f32x4*>(row + C + c) = b;
@@ -351,12 +397,21 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
                                                           float* __restrict__ dy, size_t n4, int C, float inv_count,
                                                           float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift) {
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ slots, float* __restrict__ sums_out) {
+    __shared__ __attribute__((aligned(16))) float s_tot[2 * 1024];      // C <= 1024 (C/4 divides 256)
     {   // blockIdx.y = group
         const size_t go = (size_t)blockIdx.y * n4 * 4, po = (size_t)blockIdx.y * 4 * C;
         du += go; y += go; dy += go; mean += po; invstd += po;
         if (scale) { scale += po; shift += po; }
-        sums += (size_t)blockIdx.y * 2 * C;
+        if (sums) sums += (size_t)blockIdx.y * 2 * C;
+    }
+    if (slots) {                                        // dvs_bn_bwd: the totals come from the copies the reduce kernel added into
+        slot_totals(slots, blockIdx.y, C, s_tot);
+        __syncthreads();
+        sums = s_tot;
+        if (blockIdx.x == 0 && sums_out)
+            for (int c = threadIdx.x; c < 2 * C; c += NT) sums_out[(size_t)blockIdx.y * 2 * C + c] = s_tot[c];
     }
     if (blockIdx.x == 0 && dgamma_acc) {               // gradient sink: d gamma / d beta added straight into .grad
         for (int c = threadIdx.x; c < C; c += NT) {     // (atomics: the groups of one launch add to the same parameters)
@@ -365,15 +420,20 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
         }
     }
     size_t stride = (size_t)gridDim.x * NT;
+    // a lane's four channels are the same in every grid-stride iteration (C/4 divides the 256 threads): per-channel values once
+    const int c = (int)(((size_t)threadIdx.x * 4) % C);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f};
+    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c);
+        sh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
     for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
-        int c = (int)((i * 4) % C);
         f32x4 g = reinterpret_cast<const f32x4*>(du)[i], yy = reinterpret_cast<const f32x4*>(y)[i];
-        f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-        f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c), s1 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        f32x4 ga = {1.f, 1.f, 1.f, 1.f};
-        if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
         if (scale) {                                    // `du` is dz: the ReLU mask is recomputed from y as in the reduction
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = yy[j] * sc[j] + sh[j] > 0.f ? g[j] : 0.f;
         }
@@ -498,7 +558,6 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) float red[];        // [NT][8]
     const int grp = blockIdx.y;
     fin += (size_t)grp * 4 * C;
-    partials += (size_t)grp * gridDim.x * 2 * C;
     const int cv = C / 4, tid = threadIdx.x;
     const int rl = tid / cv, cq = tid % cv, c = cq * 4, rlanes = NT / cv;
     const int HWo = Ho * Wo, b0 = grp * per_group;
@@ -534,9 +593,7 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_kernel(const float* __r
                 bsum[j] += o[4 + j];
             }
         }
-        float* row = partials + (size_t)blockIdx.x * 2 * C;
-        *reinterpret_cast<f32x4*>(row + c) = a;
-        *reinterpret_cast<f32x4*>(row + C + c) = bsum;
+        slot_add(partials, grp, blockIdx.x, C, c, a, bsum);      // `partials` = the zero-filled [G][BWD_SLOTS][2][C] table
     }
 }
 
@@ -546,10 +603,16 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_apply_kernel(const float* __re
                                                                const float* __restrict__ fin, const float* __restrict__ gamma,
                                                                const float* __restrict__ sums, float* __restrict__ dy, int Mb, int C,
                                                                int H, int W, int Ho, int Wo, int per_group, float inv_count,
-                                                               float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
+                                                               float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc,
+                                                               float* __restrict__ sums_out) {
+    __shared__ __attribute__((aligned(16))) float s_tot[2 * 1024];
     const int grp = blockIdx.y;
     fin += (size_t)grp * 4 * C;
-    sums += (size_t)grp * 2 * C;
+    slot_totals(sums, grp, C, s_tot);                   // `sums` = the slot table the reduce kernel added into
+    __syncthreads();
+    if (blockIdx.x == 0 && sums_out)
+        for (int c = threadIdx.x; c < 2 * C; c += NT) sums_out[(size_t)grp * 2 * C + c] = s_tot[c];
+    sums = s_tot;
     if (blockIdx.x == 0 && dgamma_acc) {
         for (int c = threadIdx.x; c < C; c += NT) {
             atomicAdd(dbeta_acc + c, sums[c]);
@@ -697,7 +760,7 @@ static int dvs_bn_bwd_reduce_impl(const float* dz, const float* z, const float* 
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
         hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
-                           invstd, scale, shift, du, workspace, (int)M, C, rpb);
+                           invstd, scale, shift, du, workspace, (int)M, C, rpb, nullptr);
     }
     // one slice = one ordered sum per address (deterministic mode); 32 slices = 32 float atomics per address
     const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
@@ -728,12 +791,43 @@ static int dvs_bn_bwd_apply_impl(const float* du, const float* y, const float* m
                                  const float* scale, const float* shift, void* stream) {
     DVS_REQUIRE(du && y && mean && invstd && sums && dy && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1, "dvs_bn_bwd_apply: bad argument");
     DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_bwd_apply: gradient sinks come together");
+    DVS_REQUIRE(C / 4 <= NT && (NT % (C / 4)) == 0, "dvs_bn_bwd_apply: C/4 must divide 256 (C=%d)", C);
     size_t n4 = M * C / 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, du, y, mean, invstd, gamma, sums, dy, n4,
-                       C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc, scale, shift);
+                       C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc, scale, shift, nullptr, nullptr);
     return dvs::check_launch("dvs_bn_bwd_apply");
+}
+
+int dvs_bn_bwd_slot_floats(int C, int groups) { return (C > 0 && groups > 0) ? groups * BWD_SLOTS * 2 * C : 0; }
+
+int dvs_bn_bwd(const float* dz, const float* z, const float* y, const float* fin, int ymask, const float* gamma, float* du, float* dy,
+               float* slot_table, float* sums_out, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups, void* stream) {
+    DVS_REQUIRE(dz && y && fin && dy && slot_table && M > 0 && C > 0 && (C & 3) == 0 && groups >= 1, "dvs_bn_bwd: bad argument");
+    const int cv = C / 4;
+    DVS_REQUIRE(cv <= NT && (NT % cv) == 0, "dvs_bn_bwd: C/4 must divide 256 (C=%d)", C);
+    DVS_REQUIRE(M < 2147483648ull, "dvs_bn_bwd: too many rows");
+    DVS_REQUIRE(!(ymask && (z || du)), "dvs_bn_bwd: the y-mask form neither reads z nor writes du");
+    DVS_REQUIRE((dgamma_acc == nullptr) == (dbeta_acc == nullptr), "dvs_bn_bwd: gradient sinks come together");
+    const float *scale = fin, *shift = fin + C, *mean = fin + 2 * C, *invstd = fin + 3 * C;     // rows of group 0; 4C per group
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks, rpb;
+    bn_reduce_geometry(M, C, &blocks, &rpb);
+    {
+        dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dz, z, y, mean,
+                           invstd, ymask ? scale : nullptr, ymask ? shift : nullptr, du, nullptr, (int)M, C, rpb, slot_table);
+    }
+    {
+        const size_t n4 = M * C / 4;
+        dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
+        // the masked gradient: du when the reduce pass wrote it, else dz (masked again from y in the y-mask form, or unmasked: no ReLU)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4), groups), dim3(NT), 0, st, du ? du : dz, y, mean, invstd, gamma,
+                           nullptr, dy, n4, C, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc, ymask ? scale : nullptr,
+                           ymask ? shift : nullptr, slot_table, sums_out);
+    }
+    return dvs::check_launch("dvs_bn_bwd");
 }
 
 int dvs_bn_relu_maxpool_fwd(const float* y, const float* fin, float* z, float* pooled, unsigned char* idx, int B, int H, int W, int C,
@@ -765,20 +859,18 @@ int dvs_bn_relu_maxpool_bwd(const float* dpool, const unsigned char* idx, const 
     const size_t Mb = (size_t)(B / groups) * Ho * Wo;     // 2x2 blocks per group (one per pooled pixel)
     hipStream_t st = static_cast<hipStream_t>(stream);
     int blocks, rpb;
-    bn_reduce_geometry(Mb, C, &blocks, &rpb);             // <= the partial rows dvs_bn_bwd_workspace(M, C, groups) provides
+    bn_reduce_geometry(Mb, C, &blocks, &rpb);
     const unsigned* ix = reinterpret_cast<const unsigned*>(idx);
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
         hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3((unsigned)blocks, groups), dim3(NT), NT * 8 * sizeof(float), st, dpool, ix,
                            dz_extra, y, fin, workspace, (int)Mb, C, H, W, Ho, Wo, B / groups, rpb);
     }
-    const int slices = (blocks >= 64 && !dvs::deterministic()) ? 32 : 1, rps = (blocks + slices - 1) / slices;
-    hipLaunchKernelGGL(bn_bwd_sum_partials_kernel, dim3((2 * C + NT - 1) / NT, slices, groups), dim3(NT), 0, st, workspace, sums, blocks,
-                       2 * C, rps);
     {
         dvs::ProfScope prof(dvs::SLOT_BN_BWD, st);
         hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(stream_grid(Mb * cv), groups), dim3(NT), 0, st, dpool, ix, dz_extra, y, fin,
-                           gamma, sums, dy, (int)Mb, C, H, W, Ho, Wo, B / groups, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc);
+                           gamma, workspace, dy, (int)Mb, C, H, W, Ho, Wo, B / groups, (float)(1.0 / (double)M), dgamma_acc, dbeta_acc,
+                           sums);
     }
     return dvs::check_launch("dvs_bn_relu_maxpool_bwd");
 }

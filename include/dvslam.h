@@ -290,9 +290,19 @@ int dvs_bn_bwd_apply(const float* du, const float* y, const float* mean, const f
  *        dvs_maxpool3x3s2_fwd would give on z = relu(y*scale+shift); z [B,H,W,C] is written only when non-NULL (DepthNet's
  *        finest skip connection reads it; PoseNet never does).
  *   bwd: dz = maxpool gradient (gathered from dpool / idx, never stored) + dz_extra (NULL or [B,H,W,C]: the gradient of z's
- *        other consumer), ReLU mask recomputed from y; sums [G][2][C] (zero-filled by the caller) receive sum(dz), sum(dz*xhat);
+ *        other consumer), ReLU mask recomputed from y; sums [G][2][C] receive sum(dz), sum(dz*xhat);
  *        dy [B,H,W,C] = training-mode BatchNorm backward; dgamma_acc / dbeta_acc as in dvs_bn_bwd_apply.  workspace:
- *        dvs_bn_bwd_workspace((B/G)*H*W, C, G) bytes.  C/4 must divide 256. */
+ *        dvs_bn_bwd_slot_floats(C, G) ZERO-FILLED floats (the slot table of dvs_bn_bwd); sums [G][2][C] is written, not
+ *        accumulated.  C/4 must divide 256. */
+/* (ABI 5) reduce + apply without the kernel in between that adds the per-workgroup partial rows: `slot_table` =
+ *   dvs_bn_bwd_slot_floats(C, groups) zero-filled floats ([G][32][2][C]); workgroup w of the reduce pass adds its partial sums into
+ *   copy w % 32 and every workgroup of the apply pass adds the copies up.  fin = the forward's [G][4][C] table.  ymask != 0: ReLU
+ *   without a residual, the mask recomputed from y (z and du must be NULL); else z (NULL = no ReLU) masks dz and du (NULL = not
+ *   needed) receives dz * [z > 0].  sums_out (NULL = skip): [G][2][C] = sum(du), sum(du * xhat) for callers that hand d beta /
+ *   d gamma to autograd.  The deterministic mode (dvs_set_deterministic) keeps dvs_bn_bwd_reduce / _apply with their ordered sum. */
+int dvs_bn_bwd_slot_floats(int C, int groups);
+int dvs_bn_bwd(const float* dz, const float* z, const float* y, const float* fin, int ymask, const float* gamma, float* du, float* dy,
+               float* slot_table, float* sums_out, size_t M, int C, float* dgamma_acc, float* dbeta_acc, int groups, void* stream);
 int dvs_bn_relu_maxpool_fwd(const float* y, const float* fin, float* z, float* pooled, unsigned char* idx, int B, int H, int W, int C,
                             int groups, void* stream);
 int dvs_bn_relu_maxpool_bwd(const float* dpool, const unsigned char* idx, const float* dz_extra, const float* y, const float* fin,

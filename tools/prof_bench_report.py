@@ -38,9 +38,9 @@ def family(n):
         return "conv_fwd_kernel"
     if "thin_dgrad" in n or "reflect_fold" in n or "act_bwd" in n:
         return "conv_dgrad_kernel"
-    if "bn_bwd" in n:
+    if "bn_bwd" in n or "bn_pool_bwd" in n:
         return "bn_bwd_kernel"
-    if "bn_apply_fwd" in n or "bn_finalize" in n or "bn_fwd_fused" in n:
+    if "bn_apply_fwd" in n or "bn_finalize" in n or "bn_fwd_fused" in n or "bn_relu_maxpool_fwd" in n:
         return "bn_fwd_kernel"
     return base.split("<")[0][-48:]
 
