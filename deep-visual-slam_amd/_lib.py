@@ -12,7 +12,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
 MAX_SCALES = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp = C.c_void_p
 
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "dvs_wino_weights": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 13 + [_vp]),
     "dvs_conv3x3_wino_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "dvs_conv3x3_wino_wgrad_gen": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),

@@ -350,6 +350,43 @@ def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
     return None if dw_out is not None else dw
 
 
+_WINO_DEC_WGRAD = os.environ.get("DVS_WINOGRAD_DECODER_WGRAD", "1") != "0"
+
+
+def wino_dec_wgrad_eligible(weight_shape, x, x2):
+    """The decoder's wide Conv3x3 layers (the ones wino_dec_eligible sends to the Winograd forward) whose sources split into
+    32-channel blocks: their weight gradient runs on the Winograd kernel's reflect / upsample gathers."""
+    co, ci = weight_shape[:2]
+    c2 = x2.shape[1] if isinstance(x2, torch.Tensor) else 0
+    return (_WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
+            and x.shape[1] + c2 == ci and x.shape[2] * (1 if x2 is None else 2) >= 2 and x.shape[3] * (1 if x2 is None else 2) >= 2)
+
+
+def conv3x3_wino_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False):
+    """Weight gradient of ReflectionPad2d(1) + [nearest 2x upsample of x (+ concat with x2)] + 3x3 (model/layers.py:26-41,
+    model/depth_decoder.py:52-62) on the Winograd kernel; dy is the gradient in front of the activation.  x2: None,
+    UPSAMPLE_ONLY or the skip tensor.  dw_out: gradient sink to add into (returns None)."""
+    x, dy = _nhwc(x), _nhwc(dy)
+    co, ci = weight_shape[:2]
+    up = x2 is not None
+    skip = _nhwc(x2) if isinstance(x2, torch.Tensor) else None
+    B, c1, hs, ws = x.shape
+    H, W = (2 * hs, 2 * ws) if up else (hs, ws)
+    c2 = skip.shape[1] if skip is not None else 0
+    if c1 + c2 != ci or tuple(dy.shape) != (B, co, H, W) or (skip is not None and tuple(skip.shape) != (B, c2, H, W)):
+        raise _lib.DvsError("conv3x3_wino_wgrad_gen: operands %s / %s / dy %s do not fit a %s weight at %dx%d"
+                            % (tuple(x.shape), None if skip is None else tuple(skip.shape), tuple(dy.shape), tuple(weight_shape), H, W))
+    if dw_out is not None:
+        if tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
+            raise _lib.DvsError("conv3x3_wino_wgrad_gen: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
+        dw = dw_out
+    else:
+        dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
+    check(_lib.lib().dvs_conv3x3_wino_wgrad_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(), dw.data_ptr(),
+                                                B, H, W, c1, c2, co, int(up), _WINO_WGS, _lib.stream()), "dvs_conv3x3_wino_wgrad_gen")
+    return None if dw_out is not None else dw
+
+
 def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False, residual=None):
     """dx [B,Cin,H,W] (NHWC) of a forward conv described by (weight, x_shape, stride, pad, reflect).
     split_c1 > 0 (upsample+concat forward, x_shape = the concatenated full-resolution input): returns
@@ -551,12 +588,17 @@ class _Conv2d(torch.autograd.Function):
             else:
                 bsink_w = bsink
             side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
+            # decoder layer on the Winograd kernels whose activation derivative and bias gradient the pre-activation pass took
+            wino_gen = (ctx.wino_dec and not ACT[act] and not want_b and reflect and stride == 1 and pad == 1
+                        and wino_dec_wgrad_eligible(weight.shape, x, x2))
             if side is None:
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, torch.cuda.current_stream())
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
                 if ctx.wino and wino_wgrad_eligible(weight.shape):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
+                elif wino_gen:
+                    dw = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 else:
                     dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                           in_scale=scale, in_shift=shift, nchw_planar=planar,
@@ -571,6 +613,8 @@ class _Conv2d(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     if ctx.wino and wino_wgrad_eligible(weight.shape):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
+                    elif wino_gen:
+                        conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink)
                     else:
                         conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                      in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink_w)

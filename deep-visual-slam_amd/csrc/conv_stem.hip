@@ -126,22 +126,24 @@ __device__ __forceinline__ void store_patch(float* patch, const PatchRegs<CIN>& 
 
 template <int CIN>
 __global__ __launch_bounds__(SNT) void stem_wgrad_kernel(StemParams p) {
-    constexpr int KT = CIN * 56;                        // (ci, ky, kx8)
-    constexpr int NT32 = (KT + 31) / 32;                // 32-wide N tiles: 6 / 11
-    constexpr int TNW = (NT32 + 1) / 2;                 // per wave (2 waves along N): 3 / 6
+    constexpr int KT = CIN * 56;                        // row of dw: (ci, ky, kx8), the kx = 7 column is never written (stays zero)
+    constexpr int KD = CIN * 49;                        // the GEMM's N: the real (ci, ky, kx) columns, dense -- 147 / 294
+    constexpr int NT32 = (KD + 31) / 32;                // 32-wide N tiles: 5 / 10 (the padded rows took 6 / 11, i.e. 6 / 12 with two waves along N)
+    constexpr int TNW = (NT32 + 1) / 2;                 // per wave (2 waves along N): 3 / 5
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                // [CIN][9][136]
     float* dyt = smem + CIN * PROWS * PSTRIDE;          // [128][64]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
-    // per-lane patch offset of my column n of each N tile (clamped past the end: those results are not stored)
-    int koff[TNW];
+    // per-lane patch offset of my column n of each N tile (clamped past the end: those results are not stored) and its place in dw
+    int koff[TNW], kdst[TNW];
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
-        int n = min((wn * TNW + t) * 32 + r32, KT - 1);
-        const int kx = n & 7, row = n >> 3, ci = row / 7, ky = row - ci * 7;
+        const int n = (wn * TNW + t) * 32 + r32, nc = min(n, KD - 1);
+        const int ci = nc / 49, rem = nc - ci * 49, ky = rem / 7, kx = rem - ky * 7;
         koff[t] = (ci * PROWS + ky) * PSTRIDE + kx + 2 * h;          // + 2h: the odd pixel of a k-step is one column on
+        kdst[t] = n < KD ? (ci * 7 + ky) * 8 + kx : -1;
     }
     const int a_off = h * 64 + wm * 32 + r32;                         // dY tile: [pixel][channel]
 
@@ -195,12 +197,11 @@ __global__ __launch_bounds__(SNT) void stem_wgrad_kernel(StemParams p) {
     // D map of the 32x32 MFMA: column n = lane & 31, rows (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int t = 0; t < TNW; ++t) {
-        const int n = (wn * TNW + t) * 32 + r32;
-        if (n >= KT || (p.dbg & 1)) continue;
+        if (kdst[t] < 0 || (p.dbg & 1)) continue;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int co = wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            atomicAdd(p.dw + (size_t)co * KT + n, acc[t][i]);
+            atomicAdd(p.dw + (size_t)co * KT + kdst[t], acc[t][i]);
         }
     }
 }

@@ -486,8 +486,16 @@ struct WinoWgradParams {
     int nblk_ci, nblk;     // 32-channel blocks of Cin; blocks of (Cout, Cin)
     int S;                 // splits of the tile range over workgroups
     int tiles_per_wg;      // multiple of 16
+    int CinW;              // row stride of dw in channels (= Cin, or the concatenated channel count when x is one of two sources)
 };
 
+// MODE 0: zero padding 1 (the BasicBlock layers).  The decoder's gathers (model/layers.py:26-41, model/depth_decoder.py:52-62):
+// MODE 1: ReflectionPad2d(1) -- a patch pixel outside the image moves two rows / columns back inside instead of reading zero (the
+//         same two vector operations per offset: an add instead of an or);  MODE 2: x is the half-resolution operand of the nearest
+//         2x upsample, [B][H/2][W/2][Cin] -- the 4 x 4 patch of output tile (ty, tx) is source pixels {ty-1, ty, ty, ty+1} x
+//         {tx-1, tx, tx, tx+1}, clamped at the border (= reflection of the upsampled image): 9 loads instead of 16.
+// The two sources of an upsample + concat layer are two launches, each adding into its own channel range of dw (CinW).
+template <int MODE>
 __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     __shared__ float sR[2][256][64];                      // 128 KB: accumulators of two waves during the reduction
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -514,9 +522,15 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 
     // the x resource starts (W + 1) pixels before the tensor so that patch offsets are non-negative: pixel (i, j) of the patch of
     // a tile whose first output pixel has index pb is at pb + (i - 1) W + (j - 1); reads in front of the tensor are masked out
-    const size_t lead = (size_t)(W + 1) * Cin * 4;
+    constexpr int NX = MODE == 2 ? 9 : 16;                 // loads of one patch
+    const int Hs = MODE == 2 ? H >> 1 : H, Ws = MODE == 2 ? W >> 1 : W;      // geometry of x
+    // MODE 1 / 2 move a mirrored / clamped pixel by up to two rows and two columns (one and one) towards the front: the resource starts
+    // that much earlier still and every offset carries the shift, so that voffset alone never goes below zero (the bounds check does
+    // not wrap)
+    const unsigned kshift = MODE == 1 ? 2u * (unsigned)((W + 1) * Cin * 4) : MODE == 2 ? (unsigned)((Ws + 1) * Cin * 4) : 0u;
+    const size_t lead = (size_t)(Ws + 1) * Cin * 4 + kshift;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)((size_t)p.B * H * W * Cin * 4 + lead), 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)((size_t)p.B * Hs * Ws * Cin * 4 + lead), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
@@ -530,24 +544,57 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         ty = rem / TXn;
         tx = rem - ty * TXn;
     }
-    // offsets of the current tile's 16 + 4 loads: v | row mask | column mask, a mask being 0 (inside) or OOB (outside: the OR
+    // offsets of the current tile's 16 (9) + 4 loads: v | row mask | column mask, a mask being 0 (inside) or OOB (outside: the OR
     // lands beyond every tensor < 2 GiB); then two tiles on
-    unsigned ox_[16], oy_[4];
+    unsigned ox_[NX], oy_[4];
     auto offsets_and_advance = [&]() {
         const int oy = 2 * ty, ox = 2 * tx;
         const unsigned pb = (unsigned)((tb * H + oy) * W + ox);
-        const unsigned vx = (pb * Cin + ci0 + r) * 4u, vy = (pb * Cout + co0 + r) * 4u;
+        const unsigned vy = (pb * Cout + co0 + r) * 4u;
         const unsigned dead = t < t_end ? 0u : OOB;
-        const unsigned rm[4] = {oy >= 1 ? dead : OOB, dead, oy + 1 < H ? dead : OOB, oy + 2 < H ? dead : OOB};
-        const unsigned cm[4] = {ox >= 1 ? 0u : OOB, 0u, ox + 1 < W ? 0u : OOB, ox + 2 < W ? 0u : OOB};
+        if constexpr (MODE == 0) {
+            const unsigned vx = (pb * Cin + ci0 + r) * 4u;
+            const unsigned rm[4] = {oy >= 1 ? dead : OOB, dead, oy + 1 < H ? dead : OOB, oy + 2 < H ? dead : OOB};
+            const unsigned cm[4] = {ox >= 1 ? 0u : OOB, 0u, ox + 1 < W ? 0u : OOB, ox + 2 < W ? 0u : OOB};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ox_[4 * i + j] = vx | rm[i] | cm[j];
+                for (int j = 0; j < 4; ++j) ox_[4 * i + j] = vx | rm[i] | cm[j];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) oy_[2 * i + j] = vy | rm[1 + i] | cm[1 + j];
+                for (int j = 0; j < 2; ++j) oy_[2 * i + j] = vy | rm[1 + i] | cm[1 + j];
+        } else if constexpr (MODE == 1) {
+            // rows oy - 1 .. oy + 2: -1 -> 1, H -> H - 2 (with H odd the last tile row has oy + 1 == H: its first output row reads
+            // that mirrored row); row H + 1 only meets the masked second dY row of such a tile: it reads zero.  Columns alike.
+            const unsigned vx = (pb * Cin + ci0 + r) * 4u + kshift;
+            const unsigned rowb = (unsigned)(W * Cin * 4), colb = (unsigned)(Cin * 4);
+            const unsigned in_r = oy + 1 < H ? dead : OOB, in_c = ox + 1 < W ? 0u : OOB;
+            const unsigned rm[4] = {dead, dead, dead, in_r};
+            const unsigned cm[4] = {0u, 0u, 0u, in_c};
+            const unsigned vr[4] = {vx + (oy >= 1 ? 0u : 2u * rowb), vx, vx - (oy + 1 == H ? 2u * rowb : 0u), vx - (oy + 2 == H ? 2u * rowb : 0u)};
+            const unsigned ca[4] = {ox >= 1 ? 0u : 2u * colb, 0u, ox + 1 == W ? 0u - 2u * colb : 0u, ox + 2 == W ? 0u - 2u * colb : 0u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ox_[4 * i + j] = (vr[i] + ca[j]) | rm[i] | cm[j];
+            oy_[0] = vy | dead;
+            oy_[1] = vy | dead | in_c;
+            oy_[2] = vy | in_r;
+            oy_[3] = vy | in_r | in_c;
+        } else {
+            // source pixel (ty, tx) and its eight neighbours, clamped (H and W are even: every tile is whole)
+            const unsigned vs = (unsigned)((((tb * Hs + ty) * Ws + tx) * Cin + ci0 + r) * 4) + kshift;
+            const unsigned rowb = (unsigned)(Ws * Cin * 4), colb = (unsigned)(Cin * 4);
+            const unsigned vr[3] = {vs + (ty >= 1 ? 0u : rowb), vs, vs - (ty + 1 < Hs ? 0u : rowb)};
+            const unsigned ca[3] = {tx >= 1 ? 0u : colb, 0u, tx + 1 < Ws ? 0u : 0u - colb};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ox_[3 * i + j] = (vr[i] + ca[j]) | dead;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oy_[e] = vy | dead;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             ++tx;
@@ -560,16 +607,23 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         }
         t += 2;
     };
-    auto issue_loads = [&](float (&xd)[16], float (&yd)[4]) {
+    auto issue_loads = [&](float (&xd)[NX], float (&yd)[4]) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], ((e >> 2) * W + (e & 3)) * Cin * 4, 0));
+        for (int e = 0; e < NX; ++e) {
+            const int soff = MODE == 2 ? ((e / 3) * Ws + (e % 3)) * Cin * 4 : ((e >> 2) * W + (e & 3)) * Cin * 4;
+            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], soff, 0));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             yd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
     };
-    auto transform = [&](const float (&xc)[16], const float (&yc)[4], float (&v)[16], float (&pm)[16]) {
-        float tt[4][4], pr[4][2];
+    auto transform = [&](const float (&xs)[NX], const float (&yc)[4], float (&v)[16], float (&pm)[16]) {
+        float tt[4][4], pr[4][2], xc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {                    // MODE 2: patch row i = source row {0, 1, 1, 2}[i], columns alike
+            constexpr int dup[4] = {0, 1, 1, 2};
+            xc[e] = MODE == 2 ? xs[3 * dup[e >> 2] + dup[e & 3]] : xs[e];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                     // B^T d
             tt[0][j] = xc[j] - xc[8 + j];
@@ -607,7 +661,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
     // step k: loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from (vc, pc); (vn, pn) <- transform of rn (k+1)
-    auto kstep = [&](float (&rlx)[16], float (&rly)[4], const float (&rnx)[16], const float (&rny)[4], const float (&vc)[16],
+    auto kstep = [&](float (&rlx)[NX], float (&rly)[4], const float (&rnx)[NX], const float (&rny)[4], const float (&vc)[16],
                      const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
         __builtin_amdgcn_sched_barrier(0);
         issue_loads(rlx, rly);
@@ -622,7 +676,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
         }
     };
-    float r0x[16], r0y[4], r1x[16], r1y[4], v0[16], p0[16], v1[16], p1[16];
+    float r0x[NX], r0y[4], r1x[NX], r1y[4], v0[16], p0[16], v1[16], p1[16];
     offsets_and_advance();
     issue_loads(r0x, r0y);                                // k-step 0
     offsets_and_advance();
@@ -672,14 +726,14 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
                 t3[1][b] = 0.5f * (u[1][b] - u[2][b]);
                 t3[2][b] = hs + u[3][b];
             }
-            float* o = p.dw + (size_t)(co0 + m) * 9 * Cin + ci0 + r;
+            float* o = p.dw + (size_t)(co0 + m) * 9 * p.CinW + ci0 + r;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {                  // (G^T dU) G
                 const float hs = 0.5f * (t3[k][1] + t3[k][2]);
                 const float w3[3] = {t3[k][0] + hs, 0.5f * (t3[k][1] - t3[k][2]), hs + t3[k][3]};
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
-                    float* a = o + (size_t)(3 * k + l) * Cin;
+                    float* a = o + (size_t)(3 * k + l) * p.CinW;
                     if (exclusive) *a += w3[l];
                     else atomicAdd(a, w3[l]);
                 }
@@ -711,6 +765,30 @@ void launch_wino(WinoParams& p, hipStream_t st) {
     } else {
         hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, GEN>), dim3((unsigned)grid), dim3(NT), 0, st, p);
     }
+}
+
+// x: the source tensor of this launch (MODE 2: at half resolution); dw: already offset to the source's first channel, CinW its row stride
+template <int MODE>
+void launch_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int CinW, int target_workgroups,
+                       hipStream_t st) {
+    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0, CinW};
+    const int ntiles = B * ((H + 1) / 2) * ((W + 1) / 2);
+    // default: one round of one workgroup per CU (fewer, longer tile ranges: less reduction and atomic traffic); the 512-channel
+    // layers take two tile ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
+    if (target_workgroups <= 0) target_workgroups = p.nblk >= 256 ? 512 : 256;
+    int S = (target_workgroups + p.nblk / 2) / p.nblk;
+    S = S < 1 ? 1 : S;
+    int tpw = ((ntiles + S - 1) / S + 15) & ~15;          // tiles per workgroup: four waves x two tiles x an even number of k-steps
+    tpw = tpw < 64 ? 64 : tpw;                             // at least eight k-steps per wave
+    S = (ntiles + tpw - 1) / tpw;
+    if (S < 8) {                                           // 1, 2 or 4 ranges (the XCD map of the kernel); ranges past the end add zeros
+        S = S >= 4 ? 4 : S >= 2 ? 2 : 1;
+        tpw = ((ntiles + S - 1) / S + 15) & ~15;
+    }
+    p.tiles_per_wg = tpw;
+    p.S = S;
+    const size_t grid = S >= 8 ? (size_t)((S + 7) / 8) * 8 * p.nblk : (size_t)((p.nblk + 8 / S - 1) / (8 / S)) * 8;
+    hipLaunchKernelGGL(wino_wgrad_kernel<MODE>, dim3((unsigned)grid), dim3(NT), 0, st, p);
 }
 
 }  // namespace
@@ -796,25 +874,28 @@ int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
     prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
-    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0};
-    const int ntiles = B * ((H + 1) / 2) * ((W + 1) / 2);
-    // default: one round of one workgroup per CU (fewer, longer tile ranges: less reduction and atomic traffic); the 512-channel
-    // layers take two tile ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
-    if (target_workgroups <= 0) target_workgroups = p.nblk >= 256 ? 512 : 256;
-    int S = (target_workgroups + p.nblk / 2) / p.nblk;
-    S = S < 1 ? 1 : S;
-    int tpw = ((ntiles + S - 1) / S + 15) & ~15;          // tiles per workgroup: four waves x two tiles x an even number of k-steps
-    tpw = tpw < 64 ? 64 : tpw;                             // at least eight k-steps per wave
-    S = (ntiles + tpw - 1) / tpw;
-    if (S < 8) {                                           // 1, 2 or 4 ranges (the XCD map of the kernel); ranges past the end add zeros
-        S = S >= 4 ? 4 : S >= 2 ? 2 : 1;
-        tpw = ((ntiles + S - 1) / S + 15) & ~15;
-    }
-    p.tiles_per_wg = tpw;
-    p.S = S;
-    const size_t grid = S >= 8 ? (size_t)((S + 7) / 8) * 8 * p.nblk : (size_t)((p.nblk + 8 / S - 1) / (8 / S)) * 8;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3((unsigned)grid), dim3(NT), 0, st, p);
+    launch_wino_wgrad<0>(x, dy, dw, B, H, W, Cin, Cout, Cin, target_workgroups, st);
     return dvs::check_launch("dvs_conv3x3_wino_wgrad");
+}
+
+int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, float* dw, int B, int H, int W, int C1, int C2, int Cout,
+                               int upsample, int target_workgroups, void* stream) {
+    DVS_REQUIRE(x && dy && dw && B > 0 && H >= 2 && W >= 2, "dvs_conv3x3_wino_wgrad_gen: bad argument (ReflectionPad2d(1) needs H, W >= 2)");
+    DVS_REQUIRE((C2 == 0) == (x2 == nullptr) && C2 >= 0, "dvs_conv3x3_wino_wgrad_gen: x2 and C2 go together");
+    DVS_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 % 32 == 0 && Cout > 0 && Cout % 32 == 0,
+                "dvs_conv3x3_wino_wgrad_gen: channel counts must be multiples of 32 (got %d + %d, %d)", C1, C2, Cout);
+    DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_wino_wgrad_gen: an upsampled input has even H, W");
+    DVS_REQUIRE(upsample || C2 == 0, "dvs_conv3x3_wino_wgrad_gen: a second source comes with the upsampled first one");
+    const int cmax = (C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout;
+    DVS_REQUIRE(((double)B * H * W + 3 * W + 3) * cmax * 4 < 2147483648.0,
+                "dvs_conv3x3_wino_wgrad_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
+    prof.work(2.0 * B * H * W * Cout * (double)(C1 + C2) * 9);
+    if (upsample) launch_wino_wgrad<2>(x, dy, dw, B, H, W, C1, Cout, C1 + C2, target_workgroups, st);
+    else launch_wino_wgrad<1>(x, dy, dw, B, H, W, C1, Cout, C1 + C2, target_workgroups, st);
+    if (C2) launch_wino_wgrad<1>(x2, dy, dw + C1, B, H, W, C2, Cout, C1 + C2, target_workgroups, st);
+    return dvs::check_launch("dvs_conv3x3_wino_wgrad_gen");
 }
 
 }  // extern "C"

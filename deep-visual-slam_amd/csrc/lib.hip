@@ -141,7 +141,7 @@ int dvs_set_deterministic(int on) {
 
 int dvs_get_deterministic(void) { return dvs::deterministic() ? 1 : 0; }
 
-int dvs_abi_version(void) { return 5; }
+int dvs_abi_version(void) { return 6; }
 
 const char* dvs_arch(void) { return "gfx950"; }
 
