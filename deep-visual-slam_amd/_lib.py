@@ -62,7 +62,7 @@ _SIGNATURES = {
     "dvs_wino_weights": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 13 + [_vp]),
     "dvs_conv3x3_wino_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
-    "dvs_conv3x3_wino_wgrad_gen": (C.c_int, [_vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
+    "dvs_conv3x3_wino_wgrad_gen": (C.c_int, [_vp] * 6 + [C.c_int] * 9 + [_vp]),
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),

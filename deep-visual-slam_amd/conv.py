@@ -358,14 +358,25 @@ def wino_dec_wgrad_eligible(weight_shape, x, x2):
     32-channel blocks: their weight gradient runs on the Winograd kernel's reflect / upsample gathers."""
     co, ci = weight_shape[:2]
     c2 = x2.shape[1] if isinstance(x2, torch.Tensor) else 0
-    return (_WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
-            and x.shape[1] + c2 == ci and x.shape[2] * (1 if x2 is None else 2) >= 2 and x.shape[3] * (1 if x2 is None else 2) >= 2)
+    up = 1 if x2 is None else 2
+    return (_WINO and _WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
+            and x.shape[1] + c2 == ci and x.shape[2] * up >= 2 and x.shape[3] * up >= 2
+            and (x.shape[0] * x.shape[2] * x.shape[3] * up * up + 3 * x.shape[3] * up + 3) * max(co, x.shape[1], c2) * 4 < 2 ** 31)
 
 
-def conv3x3_wino_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False):
+def wino_dec_wgrad_pays(B, H, W, k, n):
+    """Enough work for one round of workgroups (256 x four waves x eight k-steps of two tiles) over the (tile range, 32 x 32
+    channel block) pairs: below that the split-K implicit-GEMM / row-ring kernels are faster (tools/dec_wgrad_bench.py: even at
+    batch 2 every decoder layer of the 480 x 640 network is above it)."""
+    return _WINO_FORCE or B * ((H + 1) // 2) * ((W + 1) // 2) * (k // 32) * (n // 32) >= 16384
+
+
+def conv3x3_wino_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False, y_out=None, act=None, want_bias=False, db_out=None):
     """Weight gradient of ReflectionPad2d(1) + [nearest 2x upsample of x (+ concat with x2)] + 3x3 (model/layers.py:26-41,
-    model/depth_decoder.py:52-62) on the Winograd kernel; dy is the gradient in front of the activation.  x2: None,
-    UPSAMPLE_ONLY or the skip tensor.  dw_out: gradient sink to add into (returns None)."""
+    model/depth_decoder.py:52-62) on the Winograd kernel.  act None: dy is the gradient in front of the activation; "elu" /
+    "relu": dy is multiplied by act'(y_out) as it is loaded and the bias gradient (want_bias, or the sink db_out) taken on the
+    way.  x2: None, UPSAMPLE_ONLY or the skip tensor.  dw_out / db_out: gradient sinks to add into.  Returns (dw, db), None
+    where a sink took it."""
     x, dy = _nhwc(x), _nhwc(dy)
     co, ci = weight_shape[:2]
     up = x2 is not None
@@ -376,15 +387,22 @@ def conv3x3_wino_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False):
     if c1 + c2 != ci or tuple(dy.shape) != (B, co, H, W) or (skip is not None and tuple(skip.shape) != (B, c2, H, W)):
         raise _lib.DvsError("conv3x3_wino_wgrad_gen: operands %s / %s / dy %s do not fit a %s weight at %dx%d"
                             % (tuple(x.shape), None if skip is None else tuple(skip.shape), tuple(dy.shape), tuple(weight_shape), H, W))
+    dact = ACT[act]
+    if (want_bias or db_out is not None) and not dact:
+        raise _lib.DvsError("conv3x3_wino_wgrad_gen: the bias gradient rides on the activation-derivative path")
+    if dact and (y_out is None or tuple(y_out.shape) != tuple(dy.shape)):
+        raise _lib.DvsError("conv3x3_wino_wgrad_gen: the activation derivative needs the forward output")
     if dw_out is not None:
         if tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
             raise _lib.DvsError("conv3x3_wino_wgrad_gen: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
         dw = dw_out
     else:
         dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
-    check(_lib.lib().dvs_conv3x3_wino_wgrad_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(), dw.data_ptr(),
-                                                B, H, W, c1, c2, co, int(up), _WINO_WGS, _lib.stream()), "dvs_conv3x3_wino_wgrad_gen")
-    return None if dw_out is not None else dw
+    db = db_out if db_out is not None else (zeropool.zeros((co,), dy.device, pooled=pooled) if want_bias else None)
+    check(_lib.lib().dvs_conv3x3_wino_wgrad_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(),
+                                                _nhwc(y_out).data_ptr() if dact else None, dw.data_ptr(), ptr(db), B, H, W, c1, c2, co,
+                                                int(up), dact, _WINO_WGS, _lib.stream()), "dvs_conv3x3_wino_wgrad_gen")
+    return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
 def conv2d_dgrad(dy, weight, x_shape, stride, pad, reflect, y_out=None, act=None, split_c1=0, prepadded=False, residual=None):
@@ -589,8 +607,12 @@ class _Conv2d(torch.autograd.Function):
                 bsink_w = bsink
             side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
             # decoder layer on the Winograd kernels whose activation derivative and bias gradient the pre-activation pass took
-            wino_gen = (ctx.wino_dec and not ACT[act] and not want_b and reflect and stride == 1 and pad == 1
-                        and wino_dec_wgrad_eligible(weight.shape, x, x2))
+            # decoder layers (wide ones: activation derivative and bias gradient already taken by the pre-activation pass; thin
+            # ones with 32-channel blocks: both fused into the kernel's dY loads) on the Winograd kernel's reflect / upsample gathers
+            wino_gen = (reflect and stride == 1 and pad == 1 and not planar and scale is None and weight.shape[2] == 3
+                        and weight.shape[3] == 3 and act in (None, "elu", "relu") and (ACT[act] or not want_b)
+                        and wino_dec_wgrad_eligible(weight.shape, x, x2)
+                        and wino_dec_wgrad_pays(dy.shape[0], dy.shape[2], dy.shape[3], weight.shape[1], weight.shape[0]))
             if side is None:
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, torch.cuda.current_stream())
@@ -598,7 +620,8 @@ class _Conv2d(torch.autograd.Function):
                 if ctx.wino and wino_wgrad_eligible(weight.shape):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 elif wino_gen:
-                    dw = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
+                    dw, db = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight), y_out=y,
+                                                    act=act, want_bias=want_b, db_out=bsink_w)
                 else:
                     dw, db = conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                           in_scale=scale, in_shift=shift, nchw_planar=planar,
@@ -614,7 +637,7 @@ class _Conv2d(torch.autograd.Function):
                     if ctx.wino and wino_wgrad_eligible(weight.shape):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
                     elif wino_gen:
-                        conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink)
+                        conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, y_out=y, act=act, db_out=bsink_w)
                     else:
                         conv2d_wgrad(x, dy, tuple(weight.shape), stride, pad, reflect, want_b, y, act, x2=x2,
                                      in_scale=scale, in_shift=shift, dw_out=wsink, db_out=bsink_w)

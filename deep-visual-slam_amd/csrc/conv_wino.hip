@@ -487,6 +487,9 @@ struct WinoWgradParams {
     int S;                 // splits of the tile range over workgroups
     int tiles_per_wg;      // multiple of 16
     int CinW;              // row stride of dw in channels (= Cin, or the concatenated channel count when x is one of two sources)
+    const float* yact;     // DACT: the forward output y [B][H][W][Cout]; dy is multiplied by act'(y) as it is loaded
+    int dact;              // activation code of conv_common.h (1 ReLU, 2 ELU)
+    float* dbias;          // DACT: null, or [Cout] += the column sums of dy act'(y) (taken by the workgroups of input-channel block 0)
 };
 
 // MODE 0: zero padding 1 (the BasicBlock layers).  The decoder's gathers (model/layers.py:26-41, model/depth_decoder.py:52-62):
@@ -495,7 +498,9 @@ struct WinoWgradParams {
 //         2x upsample, [B][H/2][W/2][Cin] -- the 4 x 4 patch of output tile (ty, tx) is source pixels {ty-1, ty, ty, ty+1} x
 //         {tx-1, tx, tx, tx+1}, clamped at the border (= reflection of the upsampled image): 9 loads instead of 16.
 // The two sources of an upsample + concat layer are two launches, each adding into its own channel range of dw (CinW).
-template <int MODE>
+// DACT (the thin decoder layers, whose gradient kernels apply the activation derivative themselves): dZ = dY act'(Y) is formed from
+// four more loads per tile and the bias gradient rides along.
+template <int MODE, bool DACT = false>
 __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     __shared__ float sR[2][256][64];                      // 128 KB: accumulators of two waves during the reduction
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -523,6 +528,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     // the x resource starts (W + 1) pixels before the tensor so that patch offsets are non-negative: pixel (i, j) of the patch of
     // a tile whose first output pixel has index pb is at pb + (i - 1) W + (j - 1); reads in front of the tensor are masked out
     constexpr int NX = MODE == 2 ? 9 : 16;                 // loads of one patch
+    constexpr int NY = DACT ? 8 : 4;                       // dY (and Y) values of one tile
     const int Hs = MODE == 2 ? H >> 1 : H, Ws = MODE == 2 ? W >> 1 : W;      // geometry of x
     // MODE 1 / 2 move a mirrored / clamped pixel by up to two rows and two columns (one and one) towards the front: the resource starts
     // that much earlier still and every offset carries the shift, so that voffset alone never goes below zero (the bounds check does
@@ -533,7 +539,10 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)((size_t)p.B * Hs * Ws * Cin * 4 + lead), 0x00020000);
     const __amdgpu_buffer_rsrc_t yr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DACT ? p.yact : p.dy), 0,
+                                                                        (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
     constexpr unsigned OOB = 0xC0000000u;
+    float bsum = 0.f;                                      // DACT: my channel's sum of dZ over my tiles
 
     // my tile of k-step k: t_begin + 2 k + h
     int t = t_begin + h, tb, ty, tx;
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         }
         t += 2;
     };
-    auto issue_loads = [&](float (&xd)[NX], float (&yd)[4]) {
+    auto issue_loads = [&](float (&xd)[NX], float (&yd)[NY]) {
 #pragma unroll
         for (int e = 0; e < NX; ++e) {
             const int soff = MODE == 2 ? ((e / 3) * Ws + (e % 3)) * Cin * 4 : ((e >> 2) * W + (e & 3)) * Cin * 4;
@@ -616,9 +625,23 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             yd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
+        if constexpr (DACT) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                yd[4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
+        }
     };
-    auto transform = [&](const float (&xs)[NX], const float (&yc)[4], float (&v)[16], float (&pm)[16]) {
-        float tt[4][4], pr[4][2], xc[16];
+    auto transform = [&](const float (&xs)[NX], const float (&yl)[NY], float (&v)[16], float (&pm)[16]) {
+        float tt[4][4], pr[4][2], xc[16], yc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            yc[e] = yl[e];
+            if constexpr (DACT) {                         // ELU: 1 + min(y, 0); ReLU: [y > 0]  (a masked pixel has dY = Y = 0)
+                const float ya = yl[NY - 4 + e];
+                yc[e] = p.dact == kActElu ? fmaf(yc[e], fminf(ya, 0.f), yc[e]) : (ya > 0.f ? yc[e] : 0.f);
+                bsum += yc[e];
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {                    // MODE 2: patch row i = source row {0, 1, 1, 2}[i], columns alike
             constexpr int dup[4] = {0, 1, 1, 2};
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
     // step k: loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from (vc, pc); (vn, pn) <- transform of rn (k+1)
-    auto kstep = [&](float (&rlx)[NX], float (&rly)[4], const float (&rnx)[NX], const float (&rny)[4], const float (&vc)[16],
+    auto kstep = [&](float (&rlx)[NX], float (&rly)[NY], const float (&rnx)[NX], const float (&rny)[NY], const float (&vc)[16],
                      const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
         __builtin_amdgcn_sched_barrier(0);
         issue_loads(rlx, rly);
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
         }
     };
-    float r0x[NX], r0y[4], r1x[NX], r1y[4], v0[16], p0[16], v1[16], p1[16];
+    float r0x[NX], r0y[NY], r1x[NX], r1y[NY], v0[16], p0[16], v1[16], p1[16];
     offsets_and_advance();
     issue_loads(r0x, r0y);                                // k-step 0
     offsets_and_advance();
@@ -689,6 +712,13 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    if constexpr (DACT) {
+        // every tile's dZ went through transform() exactly once per (output-channel, input-channel) block: block column 0 reports
+        if (p.dbias && ci0 == 0) {
+            const float b2 = bsum + __shfl_xor(bsum, 32, 64);
+            if (h == 0) atomicAdd(p.dbias + co0 + r, b2);
+        }
+    }
     // ---- add the four waves' accumulators: waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds
     if (wave >= 2) {
 #pragma unroll
@@ -768,10 +798,10 @@ void launch_wino(WinoParams& p, hipStream_t st) {
 }
 
 // x: the source tensor of this launch (MODE 2: at half resolution); dw: already offset to the source's first channel, CinW its row stride
-template <int MODE>
+template <int MODE, bool DACT = false>
 void launch_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int CinW, int target_workgroups,
-                       hipStream_t st) {
-    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0, CinW};
+                       hipStream_t st, const float* yact = nullptr, int dact = 0, float* dbias = nullptr) {
+    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0, CinW, yact, dact, dbias};
     const int ntiles = B * ((H + 1) / 2) * ((W + 1) / 2);
     // default: one round of one workgroup per CU (fewer, longer tile ranges: less reduction and atomic traffic); the 512-channel
     // layers take two tile ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
@@ -788,7 +818,7 @@ void launch_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H,
     p.tiles_per_wg = tpw;
     p.S = S;
     const size_t grid = S >= 8 ? (size_t)((S + 7) / 8) * 8 * p.nblk : (size_t)((p.nblk + 8 / S - 1) / (8 / S)) * 8;
-    hipLaunchKernelGGL(wino_wgrad_kernel<MODE>, dim3((unsigned)grid), dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((wino_wgrad_kernel<MODE, DACT>), dim3((unsigned)grid), dim3(NT), 0, st, p);
 }
 
 }  // namespace
@@ -878,23 +908,33 @@ int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, in
     return dvs::check_launch("dvs_conv3x3_wino_wgrad");
 }
 
-int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, float* dw, int B, int H, int W, int C1, int C2, int Cout,
-                               int upsample, int target_workgroups, void* stream) {
+int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
+                               int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, void* stream) {
     DVS_REQUIRE(x && dy && dw && B > 0 && H >= 2 && W >= 2, "dvs_conv3x3_wino_wgrad_gen: bad argument (ReflectionPad2d(1) needs H, W >= 2)");
     DVS_REQUIRE((C2 == 0) == (x2 == nullptr) && C2 >= 0, "dvs_conv3x3_wino_wgrad_gen: x2 and C2 go together");
     DVS_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 % 32 == 0 && Cout > 0 && Cout % 32 == 0,
                 "dvs_conv3x3_wino_wgrad_gen: channel counts must be multiples of 32 (got %d + %d, %d)", C1, C2, Cout);
     DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_wino_wgrad_gen: an upsampled input has even H, W");
     DVS_REQUIRE(upsample || C2 == 0, "dvs_conv3x3_wino_wgrad_gen: a second source comes with the upsampled first one");
+    DVS_REQUIRE(dact == 0 || ((dact == kActRelu || dact == kActElu) && y_out),
+                "dvs_conv3x3_wino_wgrad_gen: activation %d (0, 1 = ReLU, 2 = ELU; with the forward output)", dact);
+    DVS_REQUIRE(!dbias || dact, "dvs_conv3x3_wino_wgrad_gen: the bias gradient rides on the activation-derivative path (dact != 0)");
     const int cmax = (C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout;
     DVS_REQUIRE(((double)B * H * W + 3 * W + 3) * cmax * 4 < 2147483648.0,
                 "dvs_conv3x3_wino_wgrad_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
     prof.work(2.0 * B * H * W * Cout * (double)(C1 + C2) * 9);
-    if (upsample) launch_wino_wgrad<2>(x, dy, dw, B, H, W, C1, Cout, C1 + C2, target_workgroups, st);
-    else launch_wino_wgrad<1>(x, dy, dw, B, H, W, C1, Cout, C1 + C2, target_workgroups, st);
-    if (C2) launch_wino_wgrad<1>(x2, dy, dw + C1, B, H, W, C2, Cout, C1 + C2, target_workgroups, st);
+    const int Ct = C1 + C2, tw = target_workgroups;
+    if (dact) {
+        if (upsample) launch_wino_wgrad<2, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias);
+        else launch_wino_wgrad<1, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias);
+        if (C2) launch_wino_wgrad<1, true>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st, y_out, dact, nullptr);
+    } else {
+        if (upsample) launch_wino_wgrad<2>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st);
+        else launch_wino_wgrad<1>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st);
+        if (C2) launch_wino_wgrad<1>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st);
+    }
     return dvs::check_launch("dvs_conv3x3_wino_wgrad_gen");
 }
 

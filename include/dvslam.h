@@ -164,13 +164,15 @@ int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const 
 int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
                            void* stream);
 /*   dvs_conv3x3_wino_wgrad_gen (ABI 6): the same weight gradient behind the decoder's gathers (the inputs dvs_conv3x3_wino_gen reads
- *   with reflect = 1, org = 1): dw [Cout][3][3][C1+C2] += d/dw of conv3x3(ReflectionPad2d(1)(cat(x [, x2]))) from dy [B,H,W,Cout]
- *   (the gradient in front of the activation: dvs_act_bwd), x [B,H/2,W/2,C1] when `upsample` (nearest 2x) else [B,H,W,C1], x2
- *   [B,H,W,C2] the skip (NULL / C2 = 0: none; only with `upsample`).  One launch per source, each adding into its channel range
- *   of dw.  C1, C2, Cout % 32 == 0, H, W >= 2 (even with `upsample`), tensors < 2 GiB.  Replaces the weight gradient of
- *   model/layers.py:26-41 Conv3x3 inside model/depth_decoder.py:52-62. */
-int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, float* dw, int B, int H, int W, int C1, int C2, int Cout,
-                               int upsample, int target_workgroups, void* stream);
+ *   with reflect = 1, org = 1): dw [Cout][3][3][C1+C2] += d/dw of conv3x3(ReflectionPad2d(1)(cat(x [, x2]))) from dy [B,H,W,Cout],
+ *   x [B,H/2,W/2,C1] when `upsample` (nearest 2x) else [B,H,W,C1], x2 [B,H,W,C2] the skip (NULL / C2 = 0: none; only with
+ *   `upsample`).  dact = 0: dy is the gradient in front of the activation (dvs_act_bwd took the derivative and the bias gradient);
+ *   dact = 1 (ReLU) / 2 (ELU): dy is multiplied by act'(y_out) as it is loaded (y_out [B,H,W,Cout] = the forward output) and
+ *   dbias [Cout] (NULL: none) += its column sums.  One launch per source, each adding into its channel range of dw.
+ *   C1, C2, Cout % 32 == 0, H, W >= 2 (even with `upsample`), tensors < 2 GiB.  Replaces the weight / bias gradient of
+ *   model/layers.py:26-41 Conv3x3 (+ ELU of ConvBlock, :106-118) inside model/depth_decoder.py:52-62. */
+int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
+                               int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, void* stream);
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
                          int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);

@@ -243,3 +243,12 @@ def test_winograd_cost_model_and_eligibility():
     assert not DC.wino_dec_eligible(wd, 1, 1, True, "elu", x, torch.empty(2, 32, 12, 16), False, None)     # channels do not add up
     assert not DC.wino_dec_eligible(wd, 1, 1, True, "sigmoid", x, skip, False, None)
     assert DC.wino_wgrad_eligible((128, 64, 3, 3)) and not DC.wino_wgrad_eligible((48, 64, 3, 3))
+    # decoder weight gradient on the Winograd kernel's gathers: sources in 32-channel blocks, one round of workgroups of work
+    dec = [(512, 256, 15, 20), (512, 256, 30, 40), (256, 128, 30, 40), (256, 128, 60, 80), (128, 64, 60, 80), (128, 64, 120, 160),
+           (64, 32, 120, 160), (96, 32, 240, 320)]                                 # (Cin, Cout, H, W) of upconv_4_0 ... upconv_1_1
+    assert all(DC.wino_dec_wgrad_pays(b, h, w_, ci, co) for b in (2, 4, 12) for ci, co, h, w_ in dec)
+    assert not DC.wino_dec_wgrad_pays(2, 6, 8, 64, 64) and not DC.wino_dec_wgrad_pays(1, 15, 20, 512, 256)
+    assert DC.wino_dec_wgrad_eligible((64, 128, 3, 3), x, skip) and DC.wino_dec_wgrad_eligible((32, 64, 3, 3), x, None)
+    assert not DC.wino_dec_wgrad_eligible((16, 64, 3, 3), x, None)                 # Cout in 32-blocks
+    assert not DC.wino_dec_wgrad_eligible((64, 80, 3, 3), x, torch.empty(2, 16, 12, 16))      # skip channels in 32-blocks
+    assert not DC.wino_dec_wgrad_eligible((64, 64, 3, 3), torch.empty(2, 64, 1, 8), None)     # ReflectionPad2d(1) needs two rows

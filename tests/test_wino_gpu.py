@@ -243,14 +243,33 @@ def test_decoder_weight_gradient(B, c1, c2, co, h, w):
     for wgs in (0, 1, 4096):
         old, DC._WINO_WGS = DC._WINO_WGS, wgs
         try:
-            dw = DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3))
-            assert dw.shape == ref.shape and dw.permute(0, 2, 3, 1).is_contiguous()
+            dw, db = DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3))
+            assert db is None and dw.shape == ref.shape and dw.permute(0, 2, 3, 1).is_contiguous()
             assert _rel(dw, ref) < 3e-6, wgs
             sink = torch.full((co, ci, 3, 3), 0.5, device="cuda").contiguous(memory_format=CL)
-            assert DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3), dw_out=sink) is None
+            assert DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3), dw_out=sink) == (None, None)
             assert _rel(sink - 0.5, ref) < 3e-6 + 1e-6 / float(ref.abs().max()), wgs
         finally:
             DC._WINO_WGS = old
+    # the thin layers' form: dY times the activation derivative of the forward output on load, bias gradient on the way
+    yo = torch.randn(B, co, H, W, device="cuda", generator=g).contiguous(memory_format=CL)
+    for act in ("elu", "relu"):
+        dact = (1.0 + yo.double().clamp(max=0.0)) if act == "elu" else (yo > 0).double()
+        w64 = torch.zeros(co, ci, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+        _dec_ref(x.double(), None if skip is None else skip.double(), up, w64, None, None).backward(dz.double() * dact)
+        bref = (dz.double() * dact).sum((0, 2, 3))
+        for wgs in (0, 4096):
+            old, DC._WINO_WGS = DC._WINO_WGS, wgs
+            try:
+                dw, db = DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3), y_out=yo, act=act, want_bias=True)
+                assert _rel(dw, w64.grad) < 3e-6 and _rel(db, bref) < 1e-5, (act, wgs)
+                sink, bsink = torch.full((co, ci, 3, 3), 0.5, device="cuda").contiguous(memory_format=CL), torch.full((co,), 0.25, device="cuda")
+                assert DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3), dw_out=sink, y_out=yo, act=act, db_out=bsink) == (None, None)
+                assert _rel(sink - 0.5, w64.grad) < 3e-6 + 1e-6 / float(w64.grad.abs().max()) and _rel(bsink - 0.25, bref) < 1e-5, (act, wgs)
+                dw2, none = DC.conv3x3_wino_wgrad_gen(x, x2, dz, (co, ci, 3, 3), y_out=yo, act=act)
+                assert none is None and _rel(dw2, w64.grad) < 3e-6
+            finally:
+                DC._WINO_WGS = old
 
 
 def test_decoder_weight_gradient_rejects_what_it_does_not_cover():
@@ -262,6 +281,39 @@ def test_decoder_weight_gradient_rejects_what_it_does_not_cover():
     x = torch.randn(1, 64, 1, 4, device="cuda").contiguous(memory_format=CL)
     with pytest.raises(_lib.DvsError):          # ReflectionPad2d(1) needs two rows
         DC.conv3x3_wino_wgrad_gen(x, None, torch.randn(1, 64, 1, 4, device="cuda").contiguous(memory_format=CL), (64, 64, 3, 3))
+    x = torch.randn(1, 64, 4, 4, device="cuda").contiguous(memory_format=CL)
+    with pytest.raises(_lib.DvsError):          # a bias gradient without the activation path
+        DC.conv3x3_wino_wgrad_gen(x, None, torch.randn(1, 64, 4, 4, device="cuda").contiguous(memory_format=CL), (64, 64, 3, 3), want_bias=True)
+
+
+@pytest.mark.parametrize("mode,co,c1,c2", [("skip", 32, 32, 64), ("plain", 32, 64, 0), ("skip", 64, 64, 64), ("plain", 128, 64, 0)])
+def test_decoder_layer_autograd_takes_the_winograd_weight_gradient(mode, co, c1, c2, monkeypatch):
+    """A decoder ConvBlock through conv.conv2d with the weight gradient on the Winograd gathers: thin layers (32 outputs) with the
+    ELU derivative and the bias gradient fused into it, wide ones behind the pre-activation pass; against fp64 autograd."""
+    from deep_visual_slam_amd import conv as DC
+    g = torch.Generator(device="cuda").manual_seed(13)
+    B, h, w = 2, 16, 32
+    up = mode != "plain"
+    H, W = (2 * h, 2 * w) if up else (h, w)
+    x = torch.randn(B, c1, h, w, device="cuda", generator=g).contiguous(memory_format=CL).requires_grad_(True)
+    skip = torch.randn(B, c2, H, W, device="cuda", generator=g).contiguous(memory_format=CL).requires_grad_(True) if c2 else None
+    wt = (torch.randn(co, c1 + c2, 3, 3, device="cuda", generator=g) * 0.05).contiguous(memory_format=CL).requires_grad_(True)
+    bias = (torch.randn(co, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    calls = []
+    real = DC.conv3x3_wino_wgrad_gen
+    monkeypatch.setattr(DC, "conv3x3_wino_wgrad_gen", lambda *a, **k: (calls.append(k.get("act")), real(*a, **k))[1])
+    monkeypatch.setattr(DC, "wino_dec_wgrad_pays", lambda *a: True)
+    y = DC.conv2d(x, wt, bias, 1, 0, reflect_pad=1, act="elu", x2=skip, upsample=up)
+    cot = torch.randn(y.shape, device="cuda", generator=g).contiguous(memory_format=CL)
+    ins = [x, wt, bias] + ([skip] if skip is not None else [])
+    got = torch.autograd.grad(y, ins, cot)
+    assert calls == (["elu"] if co == 32 else [None])          # fused derivative for the thin layer, pre-activation pass for the wide one
+    d = [t.detach().double().requires_grad_(True) for t in ins]
+    ref = _dec_ref(d[0], d[3] if skip is not None else None, up, d[1], d[2], "elu")
+    want = torch.autograd.grad(ref, d, cot.double())
+    assert _rel(y, ref.detach()) < TOL
+    for a, b in zip(got, want):
+        assert _rel(a, b) < 2e-5
 
 
 @pytest.mark.parametrize("mode", ["plain", "skip", "up"])

@@ -47,11 +47,16 @@ for name, c1, c2, co, h, w in LAYERS:
         F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w64).backward(dz.double())
         ref = w64.grad
     sink = torch.zeros(shape, device="cuda").contiguous(memory_format=CL)
-    dw_w = DC.conv3x3_wino_wgrad_gen(x, x2, dz, shape)
+    dw_w, _ = DC.conv3x3_wino_wgrad_gen(x, x2, dz, shape)
     dw_d, _ = DC.conv2d_wgrad(x, dz, shape, 1, 1, True, False, x2=x2)
     t_w = timeit(lambda: DC.conv3x3_wino_wgrad_gen(x, x2, dz, shape, dw_out=sink))
     t_d = timeit(lambda: DC.conv2d_wgrad(x, dz, shape, 1, 1, True, False, x2=x2, dw_out=sink))
     fl = 2.0 * B * H * W * co * ci * 9
+    if co == 32:      # the thin layers' real form: ELU derivative and bias gradient inside either kernel
+        yo = torch.randn(B, co, H, W, device="cuda", generator=g).contiguous(memory_format=CL)
+        bs = torch.zeros(co, device="cuda")
+        t_w = timeit(lambda: DC.conv3x3_wino_wgrad_gen(x, x2, dz, shape, dw_out=sink, y_out=yo, act="elu", db_out=bs))
+        t_d = timeit(lambda: DC.conv2d_wgrad(x, dz, shape, 1, 1, True, True, yo, "elu", x2=x2, dw_out=sink, db_out=bs))
     print(json.dumps(dict(layer=name, B=B, wino_us=round(t_w * 1e6, 1), direct_us=round(t_d * 1e6, 1), wino_tf=round(fl / t_w / 1e12, 1),
                           direct_tf=round(fl / t_d / 1e12, 1), wino_vs_direct=rel(dw_w, dw_d.double()),
                           err_wino=None if ref is None else rel(dw_w, ref), err_direct=None if ref is None else rel(dw_d, ref))), flush=True)
