@@ -616,12 +616,10 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         }
         t += 2;
     };
+    // dY first: the register allocator carries two of its values around the loop in other registers, and the copies at the end of
+    // the loop body wait for everything issued before them -- behind the 16 patch loads that made every second k-step wait for the
+    // whole batch it had just issued (s_waitcnt vmcnt(2) at the back edge; now vmcnt(18))
     auto issue_loads = [&](float (&xd)[NX], float (&yd)[NY]) {
-#pragma unroll
-        for (int e = 0; e < NX; ++e) {
-            const int soff = MODE == 2 ? ((e / 3) * Ws + (e % 3)) * Cin * 4 : ((e >> 2) * W + (e & 3)) * Cin * 4;
-            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], soff, 0));
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             yd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
@@ -629,6 +627,11 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 yd[4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < NX; ++e) {
+            const int soff = MODE == 2 ? ((e / 3) * Ws + (e % 3)) * Cin * 4 : ((e >> 2) * W + (e & 3)) * Cin * 4;
+            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], soff, 0));
         }
     };
     auto transform = [&](const float (&xs)[NX], const float (&yl)[NY], float (&v)[16], float (&pm)[16]) {
@@ -683,13 +686,29 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
-    // step k: loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from (vc, pc); (vn, pn) <- transform of rn (k+1)
-    auto kstep = [&](float (&rlx)[NX], float (&rly)[NY], const float (&rnx)[NX], const float (&rny)[NY], const float (&vc)[16],
-                     const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
+    // step k: the values loaded during step k-1 (k-step k+1's) move from the in-flight set rl to the staging set sn -- real moves,
+    // placed where the transform needs the data anyway; the loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from
+    // (vc, pc); (vn, pn) <- transform of sn.  With two alternating load sets the register allocator carried a few loaded values
+    // around the loop in other registers and put the copies -- hence an s_waitcnt for the batch issued in that very k-step -- at the
+    // back edge: every second k-step ran without any prefetch distance.
+    // Two in-flight sets (ra, rb) alternate, so a batch has TWO k-steps (~0.9 us) to arrive: it is issued in step k and staged in
+    // step k + 2.
+    float rax[NX], ray[NY], rbx[NX], rby[NY], snx[NX], sny[NY], v0[16], p0[16], v1[16], p1[16];
+    auto stage_loaded = [&](const float (&lx)[NX], const float (&ly)[NY]) {
+#pragma unroll
+        for (int e = 0; e < NY; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sny[e]) : "v"(ly[e]));
+#pragma unroll
+        for (int e = 0; e < NX; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(snx[e]) : "v"(lx[e]));
+    };
+    // step k: k-step k+1's values (loaded during step k-2) -> sn; loads of k+3 -> the same set; (vn, pn) <- transform of sn; offsets
+    // of k+4; MFMAs from (vc, pc)
+    auto kstep = [&](float (&lx)[NX], float (&ly)[NY], const float (&vc)[16], const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
         __builtin_amdgcn_sched_barrier(0);
-        issue_loads(rlx, rly);
+        stage_loaded(lx, ly);
         __builtin_amdgcn_sched_barrier(0);
-        transform(rnx, rny, vn, pn);
+        issue_loads(lx, ly);
+        __builtin_amdgcn_sched_barrier(0);
+        transform(snx, sny, vn, pn);
         offsets_and_advance();
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[q], vc[q], acc[q], 0, 0, 0);
@@ -699,16 +718,18 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
         }
     };
-    float r0x[NX], r0y[NY], r1x[NX], r1y[NY], v0[16], p0[16], v1[16], p1[16];
     offsets_and_advance();
-    issue_loads(r0x, r0y);                                // k-step 0
+    issue_loads(rax, ray);                                // k-step 0
     offsets_and_advance();
-    issue_loads(r1x, r1y);                                // k-step 1
-    offsets_and_advance();                                // offsets of k-step 2
-    transform(r0x, r0y, v0, p0);
+    issue_loads(rbx, rby);                                // k-step 1
+    offsets_and_advance();
+    stage_loaded(rax, ray);
+    issue_loads(rax, ray);                                // k-step 2
+    offsets_and_advance();                                // offsets of k-step 3
+    transform(snx, sny, v0, p0);
     for (int k = 0; k < ksteps; k += 2) {
-        kstep(r0x, r0y, r1x, r1y, v0, p0, v1, p1);
-        kstep(r1x, r1y, r0x, r0y, v1, p1, v0, p0);
+        kstep(rbx, rby, v0, p0, v1, p1);
+        kstep(rax, ray, v1, p1, v0, p0);
     }
     __builtin_amdgcn_sched_barrier(0);
 
