@@ -230,22 +230,26 @@ struct StemFwdParams {
 
 template <int CIN>
 __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
-    constexpr int K = CIN * 56, PN = CIN * PROWS * PSTRIDE;
+    // K runs over the real (ci, ky, kx) taps, dense: 147 / 294 instead of the packed rows' 168 / 336 (the 8th kx column multiplied a
+    // zero weight: one MFMA in eight); a k-step's two taps k = 2s + h differ irregularly between the lane halves, so the patch
+    // offset is a select between two immediates (two vector instructions per 128 cycles of MFMA).
+    constexpr int KP = CIN * 56, KD = CIN * 49, KS = (KD + 1) / 2, PN = CIN * PROWS * PSTRIDE;
     static_assert(PatchRegs<CIN>::U <= 32, "okmask is 32 bits");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* wl = smem;                    // [K][64]
-    float* patch0 = smem + K * 64;       // [2][CIN][9][136]
+    float* wl = smem;                    // [2 KS][64]
+    float* patch0 = smem + 2 * KS * 64;  // [2][CIN][9][136]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, h = lane >> 5;
-    for (int e = threadIdx.x; e < K * 64; e += SNT) {            // wl[k][co] = w[co][k]
-        const int co = e / K, k = e - co * K;
-        wl[k * 64 + co] = p.w[e];
+    for (int e = threadIdx.x; e < 2 * KS * 64; e += SNT) {       // wl[n][co] = w[co][(ci, ky, kx8)] of dense tap n (0 past the end)
+        const int n = e >> 6, co = e & 63;
+        const int ci = n / 49, rem = n - ci * 49, ky = rem / 7, kx = rem - ky * 7;
+        wl[e] = n < KD ? p.w[co * KP + (ci * 7 + ky) * 8 + kx] : 0.f;
     }
     PatchPlan<CIN> plan;
     plan.init(p.H, p.W, p.sc, p.sh);
     // per-lane bases: my two pixel rows of the patch (tile rows wm, columns tm*32 + r32) and my weight column
-    const int a_base0 = (2 * wm) * PSTRIDE + 2 * r32 + h, a_base1 = a_base0 + 64;
+    const int a_base0 = (2 * wm) * PSTRIDE + 2 * r32, a_base1 = a_base0 + 64;
     const int b_base = h * 64 + wn * 32 + r32;
 
     float ssum = 0.f, ssq = 0.f, ssum1 = 0.f, ssq1 = 0.f;
@@ -269,29 +273,31 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
-        // k = 2s + h -> (ci, ky, kx = 2 (s & 3) + h): everything but h is an immediate.  Operands are fetched two
-        // k-steps ahead into a rotating register set and the order is pinned (sched_barrier): left to itself the
-        // compiler reuses one register set and waits for every ds_read right in front of its MFMA.
-        auto koff_of = [](int s) {
-            const int row = (2 * s) >> 3, ci = row / 7, ky = row - ci * 7, kx = (2 * s) & 7;
+        // k = 2s + h -> dense tap (ci, ky, kx).  Operands are fetched two k-steps ahead into a rotating register set and the order
+        // is pinned (sched_barrier): left to itself the compiler reuses one register set and waits for every ds_read right in
+        // front of its MFMA.
+        auto koff_of = [](int n) {                           // patch offset of dense tap n (a tap past the end reads offset 0: its weight is 0)
+            const int nc = n < KD ? n : 0;
+            const int ci = nc / 49, rem = nc - ci * 49, ky = rem / 7, kx = rem - ky * 7;
             return (ci * PROWS + ky) * PSTRIDE + kx;
         };
-        constexpr int KS = K / 2, AHEAD = 2;
+        auto lane_off = [&](int s) { return h ? koff_of(2 * s + 1) : koff_of(2 * s); };
+        constexpr int AHEAD = 2;
         float ra0[AHEAD + 1], ra1[AHEAD + 1], rb[AHEAD + 1];
 #pragma unroll
         for (int s = 0; s < AHEAD; ++s) {
-            ra0[s] = patch[a_base0 + koff_of(s)];
-            ra1[s] = patch[a_base1 + koff_of(s)];
+            const int o = lane_off(s);
+            ra0[s] = patch[a_base0 + o];
+            ra1[s] = patch[a_base1 + o];
             rb[s] = wl[b_base + 2 * s * 64];
         }
         if (!(p.dbg & 4))
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + AHEAD < KS) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                ra0[(s + AHEAD) % (AHEAD + 1)] = patch[a_base0 + koff_of(s + AHEAD)];
-                ra1[(s + AHEAD) % (AHEAD + 1)] = patch[a_base1 + koff_of(s + AHEAD)];
+                const int o = lane_off(s + AHEAD);
+                ra0[(s + AHEAD) % (AHEAD + 1)] = patch[a_base0 + o];
+                ra1[(s + AHEAD) % (AHEAD + 1)] = patch[a_base1 + o];
                 rb[(s + AHEAD) % (AHEAD + 1)] = wl[b_base + 2 * (s + AHEAD) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(SNT) void stem_fwd_kernel(StemFwdParams p) {
 
 template <int CIN>
 void launch_fwd(StemFwdParams p, hipStream_t st) {
-    const size_t lds = ((size_t)CIN * 56 * 64 + 2 * CIN * PROWS * PSTRIDE) * sizeof(float);
+    const size_t lds = ((size_t)2 * ((CIN * 49 + 1) / 2) * 64 + 2 * CIN * PROWS * PSTRIDE) * sizeof(float);
     auto kern = stem_fwd_kernel<CIN>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024 - 256) {
