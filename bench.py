@@ -528,8 +528,10 @@ def main():
             roof["measured"] = ("HIP events on the launch stream, %d single-stream steps after the timed region "
                                 "(the timed steps overlap four streams)" % prof_steps)
             roof["flops_counted"] = ("algorithmic = direct-convolution flops 2*M*N*K; the stride-1 3x3 BasicBlock convolutions (26 of "
-                                     "the 53 launches of each conv slot at configs[2]) run Winograd F(2x2,3x3), which executes 2.25x "
-                                     "fewer MFMA flops than counted (DVS_WINOGRAD=0 / DVS_WINOGRAD_WGRAD=0 time the direct kernels)")
+                                     "the 53 timed scopes of each conv slot at configs[2]) and, in the weight-gradient slot, the eight "
+                                     "decoder Conv3x3 layers with 32-channel blocks run Winograd F(2x2,3x3), which executes 2.25x "
+                                     "fewer MFMA flops than counted (DVS_WINOGRAD=0 / DVS_WINOGRAD_WGRAD=0 / "
+                                     "DVS_WINOGRAD_DECODER_WGRAD=0 time the direct kernels)")
             roof.update(pmc_traffic(args.config, roof["kernel"]))
         out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
