@@ -641,9 +641,8 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         }
         t += 2;
     };
-    // dY first: the register allocator carries two of its values around the loop in other registers, and the copies at the end of
-    // the loop body wait for everything issued before them -- behind the 16 patch loads that made every second k-step wait for the
-    // whole batch it had just issued (s_waitcnt vmcnt(2) at the back edge; now vmcnt(18))
+    // one batch = the 4 (8) dY (and Y) values of my tile, then its 16 (9) patch pixels; the staging moves (stage_loaded) read them in
+    // the same order, so the waits in front of those moves count down through the batch
     auto issue_loads = [&](float (&xd)[NX], float (&yd)[NY]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
