@@ -150,6 +150,42 @@ def loss_check(trainer, sample, config):
             "source": "tests/golden/bench_loss.json (oracle networks + loss chain, PyTorch-CPU fp32, tie-break noise 0)"}
 
 
+def measured_peaks(device):
+    """The two roofline denominators measured on THIS box in THIS run (boxes differ by ~10 %): HBM by a
+    1 GiB device-to-device copy of 16 bytes per lane (2 GiB of traffic), fp32 MFMA by v_mfma_f32_32x32x2_f32 from registers on
+    every SIMD (dvs_peak_probe_*); best of 5 launches each, HIP events on the launch stream."""
+    import ctypes as C
+    from deep_visual_slam_amd import _lib
+    l = _lib.lib()
+    st = _lib.stream()
+
+    def best_ms(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        return min(ts)
+
+    nbytes = 1 << 30
+    src = torch.empty(nbytes // 4, device=device, dtype=torch.float32).normal_()
+    dst = torch.empty_like(src)
+    ms = best_ms(lambda: _lib.check(l.dvs_peak_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "dvs_peak_probe_copy"))
+    hbm = 2.0 * nbytes / (ms * 1e-3) / 1e9
+    del src, dst
+    flops = C.c_double()
+    scratch = torch.zeros(16, device=device)
+    ms = best_ms(lambda: _lib.check(l.dvs_peak_probe_mfma(scratch.data_ptr(), 8192, C.byref(flops), st), "dvs_peak_probe_mfma"))
+    mfma = flops.value / (ms * 1e-3) / 1e12
+    return {"hbm_copy_GBps": hbm, "mfma_f32_TFLOPs": mfma,
+            "how": "1 GiB float4 device copy (2 GiB traffic) and register-fed v_mfma_f32_32x32x2_f32 on every SIMD, best of 5, "
+                   "same process and box as the timed region; spec peaks stay the denominators of `frac`"}
+
+
 def pmc_traffic(config, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same command
     (tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
@@ -433,8 +469,10 @@ def main():
     from deep_visual_slam_amd import dp
 
     comm = None
-    if world > 1 and os.environ.get("DVS_ALLREDUCE", "torch") == "rccl" and not rehearse:
-        comm = dp.RcclComm(device)                # direct RCCL on a stream (hardware queue) of its own
+    # N > 1: the gradient buckets go through this repo's own RCCL C-ABI (include/dvslam_rccl.h, dp.RcclComm: a communicator on a
+    # stream -- hardware queue -- of its own); DVS_ALLREDUCE=torch is the explicit switch back to torch.distributed's process group
+    if world > 1 and os.environ.get("DVS_ALLREDUCE", "rccl") == "rccl" and not rehearse:
+        comm = dp.RcclComm(device)
     trainer, flat, sync, opt, sample = build_gpu(batch, num_scales, device, rank, comm=comm)
 
     def barrier():
@@ -533,6 +571,21 @@ def main():
                                      "fewer MFMA flops than counted (DVS_WINOGRAD=0 / DVS_WINOGRAD_WGRAD=0 / "
                                      "DVS_WINOGRAD_DECODER_WGRAD=0 time the direct kernels)")
             roof.update(pmc_traffic(args.config, roof["kernel"]))
+        peaks = measured_peaks(device)
+        if roof is not None:
+            roof["peak_measured"] = peaks["mfma_f32_TFLOPs"] if roof["bound"] == "mfma" else peaks["hbm_copy_GBps"]
+            roof["frac_of_measured"] = roof["achieved"] / roof["peak_measured"]
+        # the loss chain against the HBM roofline (45.87 MB per sample and direction
+        # for 4 scales): algorithmic bytes / kernel time of the same single-stream steps
+        chain = None
+        if "chain_fwd_kernel" in per_step and "chain_bwd_kernel" in per_step:
+            nbytes = CHAIN_FWD_BYTES[num_scales] * batch
+            chain = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "peak_measured": peaks["hbm_copy_GBps"], "unit": "GB/s",
+                     "algorithmic_bytes_per_direction": nbytes}
+            for name in ("chain_fwd_kernel", "chain_bwd_kernel"):
+                ach = nbytes / (per_step[name] * 1e-3) / 1e9
+                chain[name] = {"ms_per_step": per_step[name], "achieved": ach, "frac": ach / HBM_PEAK_GBPS,
+                               "frac_of_measured": ach / peaks["hbm_copy_GBps"], **pmc_traffic(args.config, name)}
         out = {"metric": "VO training-step frames/sec (3-frame 640x480 snippets)", "value": value,
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms_per_step, "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -540,13 +593,15 @@ def main():
                "config": {"workload": cfg["name"], "per_gpu_batch": batch, "global_batch": batch * world,
                           "num_scales": num_scales, "image": "%dx%d" % (W, H),
                           "parallelism": "dp%d" % world,
+                          "outputs": "lazy (the per-scale view-synthesis tensors of `outputs` are materialised on first access, "
+                                     "SURVEY.md section 8d; config Train.materialize_outputs times the eager variant)",
                           "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient",
                           "allreduce": (None if world == 1 else ("rccl-direct" if comm is not None else "torch.distributed " + dist.get_backend())),
                           "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
                "loss": loss_val, "loss_check": check,
                "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},
                "conv_kernels": conv_summary,
-               "roofline": roof}
+               "roofline": roof, "roofline_chain": chain, "measured_peaks": peaks}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch or batch, num_scales)
         if world == 1 and args.config == "c3" and not args.no_other_configs:

@@ -10,9 +10,9 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdvslam_hip.so")
+LIB_PATH = os.environ.get("DVS_LIB") or os.path.join(HERE, "libdvslam_hip.so")    # DVS_LIB: A/B builds (tools/build_variant.py)
 MAX_SCALES = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp = C.c_void_p
 
@@ -63,6 +63,11 @@ _SIGNATURES = {
     "dvs_conv3x3_wino_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 13 + [_vp]),
     "dvs_conv3x3_wino_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_wgrad_gen": (C.c_int, [_vp] * 6 + [C.c_int] * 9 + [_vp]),
+    "dvs_conv3x3_wino_wgrad_workspace": (C.c_size_t, [C.c_int] * 6),
+    "dvs_conv3x3_wino_wgrad_ws": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp]),
+    "dvs_conv3x3_wino_wgrad_gen_ws": (C.c_int, [_vp] * 6 + [C.c_int] * 9 + [_vp, C.c_size_t, _vp]),
+    "dvs_peak_probe_mfma": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _vp]),
+    "dvs_peak_probe_copy": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "dvs_wino_weights_batch": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_wino_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       _vp]),

@@ -328,9 +328,12 @@ _WINO_WGRAD = os.environ.get("DVS_WINOGRAD_WGRAD", "1") != "0"
 _WINO_WGS = int(os.environ.get("DVS_WINO_WGRAD_WGS", "0"))
 
 
-def wino_wgrad_eligible(weight_shape):
+def wino_wgrad_eligible(weight_shape, x=None):
+    """32-channel blocks, and operands below 1 GiB (the kernel's 32-bit offsets carry two mask bits; x: the forward input, which
+    has the output's spatial size for these stride-1 layers) -- larger ones keep the implicit-GEMM weight gradient."""
     co, ci = weight_shape[:2]
-    return _WINO_WGRAD and co % 32 == 0 and ci % 32 == 0
+    fits = x is None or (x.numel() // x.shape[1] + x.shape[3] + 1) * max(co, ci) * 4 + 8192 < 2 ** 30
+    return _WINO_WGRAD and co % 32 == 0 and ci % 32 == 0 and fits
 
 
 def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
@@ -345,9 +348,22 @@ def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
         dw = dw_out
     else:
         dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
-    check(_lib.lib().dvs_conv3x3_wino_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ci, co, _WINO_WGS,
-                                            _lib.stream()), "dvs_conv3x3_wino_wgrad")
+    ws, nws = _wgrad_workspace(B, H, W, ci, co, dy.device)
+    check(_lib.lib().dvs_conv3x3_wino_wgrad_ws(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ci, co, _WINO_WGS,
+                                               ptr(ws), nws, _lib.stream()), "dvs_conv3x3_wino_wgrad")
     return None if dw_out is not None else dw
+
+
+# Ordered weight gradient: DVS_WGRAD_ORDERED=1, or the deterministic mode (_lib.set_deterministic) -- the Winograd kernels store
+# per-workgroup partial blocks in a workspace and a second kernel adds them in a fixed order instead of float atomics on dw.
+_WGRAD_ORDERED = os.environ.get("DVS_WGRAD_ORDERED", "0") == "1"
+
+
+def _wgrad_workspace(B, H, W, ci, co, device):
+    if not (_WGRAD_ORDERED or _lib.deterministic()):
+        return None, 0
+    n = _lib.lib().dvs_conv3x3_wino_wgrad_workspace(B, H, W, ci, co, _WINO_WGS)
+    return torch.empty(max(n // 4, 1), device=device, dtype=torch.float32), n
 
 
 _WINO_DEC_WGRAD = os.environ.get("DVS_WINOGRAD_DECODER_WGRAD", "1") != "0"
@@ -361,7 +377,7 @@ def wino_dec_wgrad_eligible(weight_shape, x, x2):
     up = 1 if x2 is None else 2
     return (_WINO and _WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
             and x.shape[1] + c2 == ci and x.shape[2] * up >= 2 and x.shape[3] * up >= 2
-            and (x.shape[0] * x.shape[2] * x.shape[3] * up * up + 3 * x.shape[3] * up + 3) * max(co, x.shape[1], c2) * 4 < 2 ** 31)
+            and (x.shape[0] * x.shape[2] * x.shape[3] * up * up + 3 * x.shape[3] * up + 3) * max(co, x.shape[1], c2) * 4 + 8192 < 2 ** 30)
 
 
 def wino_dec_wgrad_pays(B, H, W, k, n):
@@ -399,9 +415,10 @@ def conv3x3_wino_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False, y
     else:
         dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
     db = db_out if db_out is not None else (zeropool.zeros((co,), dy.device, pooled=pooled) if want_bias else None)
-    check(_lib.lib().dvs_conv3x3_wino_wgrad_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(),
-                                                _nhwc(y_out).data_ptr() if dact else None, dw.data_ptr(), ptr(db), B, H, W, c1, c2, co,
-                                                int(up), dact, _WINO_WGS, _lib.stream()), "dvs_conv3x3_wino_wgrad_gen")
+    ws, nws = _wgrad_workspace(B, H, W, max(c1, c2), co, dy.device)
+    check(_lib.lib().dvs_conv3x3_wino_wgrad_gen_ws(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(),
+                                                   _nhwc(y_out).data_ptr() if dact else None, dw.data_ptr(), ptr(db), B, H, W, c1, c2, co,
+                                                   int(up), dact, _WINO_WGS, ptr(ws), nws, _lib.stream()), "dvs_conv3x3_wino_wgrad_gen")
     return (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
@@ -484,6 +501,7 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, x2, opts):
+        ctx.gs = gradsink.active()               # the stream set of the trainer that builds this graph (used in backward)
         stride, pad, reflect, act, planar, scale, shift, want_stats = opts[:8]
         passthrough = len(opts) > 8 and opts[8]  # also return x itself: its gradient (a skip path's) meets the data gradient here
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" for the statistics output
@@ -605,7 +623,7 @@ class _Conv2d(torch.autograd.Function):
                 bsink_w = None
             else:
                 bsink_w = bsink
-            side = gradsink.side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
+            side = gradsink.of(ctx).side_stream() if wsink is not None and (bsink is not None or not ctx.has_bias) else None
             # decoder layer on the Winograd kernels whose activation derivative and bias gradient the pre-activation pass took
             # decoder layers (wide ones: activation derivative and bias gradient already taken by the pre-activation pass; thin
             # ones with 32-channel blocks: both fused into the kernel's dY loads) on the Winograd kernel's reflect / upsample gathers
@@ -617,7 +635,7 @@ class _Conv2d(torch.autograd.Function):
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, torch.cuda.current_stream())
                     gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
-                if ctx.wino and wino_wgrad_eligible(weight.shape):
+                if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 elif wino_gen:
                     dw, db = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight), y_out=y,
@@ -634,7 +652,7 @@ class _Conv2d(torch.autograd.Function):
                 gradsink.note(ctx.bias_ref, cur, side)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    if ctx.wino and wino_wgrad_eligible(weight.shape):
+                    if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
                     elif wino_gen:
                         conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, y_out=y, act=act, db_out=bsink_w)
@@ -655,6 +673,7 @@ class _HeadConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pad, reflect, act, passthrough=False):
+        ctx.gs = gradsink.active()
         x_in = x
         x, w = _nhwc(x), _nhwc(weight)
         B, Cin, H, W = x.shape
@@ -678,7 +697,7 @@ class _HeadConv(torch.autograd.Function):
     def backward(ctx, dy, dxa=None):
         if dy is None:                           # (passthrough only) the head's own output was not used
             return dxa, None, None, None, None, None, None
-        gradsink.wait_pending(dy)                # a disparity gradient may still be on its way on another stream
+        gradsink.of(ctx).wait_pending(dy)        # a disparity gradient may still be on its way on another stream
         x, w, y = ctx.saved_tensors
         pad, reflect, act, has_bias = ctx.cfg
         B, Cin, H, W = x.shape

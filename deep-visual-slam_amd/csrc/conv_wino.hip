@@ -495,45 +495,66 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
 
 // ---- weight gradient:  dL/dg = G^T [ sum over tiles (A dY A^T) o (B^T d B) ] G  (the same bilinear form read for g) ------------
 // 16 GEMMs dU_xi [Cout x Cin] = sum_tiles P_xi[tile][co] * V_xi[tile][ci] with K = tiles.  A wave owns a 32 x 32 block of
-// (output channel, input channel) pairs for all 16 components (256 accumulator registers) and a range of tiles; both operands are
-// transformed in-lane from global memory (lane = one channel of one tile: 4 dY values -> 16, 4 x 4 input values -> 16; all loads
-// are dword buffer loads that are contiguous over the 32 channels of a half wave; out-of-image pixels come back as zeros from the
-// buffer bounds check).  No LDS and no barrier in the loop.  Three-stage software pipeline per k-step k: the loads of k+2 are
-// issued, the operands of k+1 are transformed and the offsets of k+3 computed between the MFMAs of k -- none of that vector work
-// depends on the MFMAs it is interleaved with.  The four waves of a workgroup split the workgroup's tile range and add their
-// accumulators through LDS; the first wave applies G^T . G in-lane (all 16 components of a (co, ci) pair sit in one lane) and
-// adds the 3 x 3 results into dw -- plain adds when the tile range is not split over workgroups, float atomics otherwise.
+// (output channel, input channel) pairs for all 16 components (256 accumulator registers) and a range of tile PAIRS; both operands
+// are transformed in-lane from global memory (lane = one channel of one tile: 4 dY values -> 16, 4 x 4 input values -> 16; all
+// loads are dword buffer loads that are contiguous over the 32 channels of a half wave).  No LDS and no barrier in the loop.
+//
+// Round 3: the fp32 MFMA runs on the vector ALU's multipliers (64 flop / clock / SIMD either way), so every vector instruction a
+// wave issues is taken out of its own matrix time (counters of the round-2 kernel: 9 % of the wave cycles parked on a counter,
+// 51 % waiting to ISSUE; 10.5 vector instructions per MFMA, of which 2.7 were the transforms).  What is left in the loop now is
+// the two transforms (44 vector instructions per 16 MFMAs) and a handful of selects:
+//   * a k-step is one PAIR of horizontally neighbouring tiles (tx = 2 txp + h, h = the lane half = the k index of the 32x32x2
+//     MFMA; a row of tiles is padded to an even count, the pad tile reads zeros), so the pair's position is wave-uniform: the
+//     byte offset of its patch origin lives in SGPRs, advances on the scalar unit and goes into the loads' soffset; a lane's
+//     voffset -- channel, lane half, patch column -- is loop invariant;
+//   * rows outside the image (or mirrored / clamped ones: MODE 1 / 2) are a scalar matter: the row's soffset, and for rows that
+//     must read zeros a buffer resource with no records (selected on the scalar unit); columns outside the image only occur in the
+//     first and the last pair of a tile row: the lanes' voffsets of those two cases are precomputed and selected by a scalar
+//     condition (7 v_cndmask per k-step);
+//   * the loaded values are transformed BEFORE their registers are loaded again (issue order is all the hardware needs), so the
+//     round-2 staging moves (20 per k-step) are gone: step k transforms the operands of k+1, then issues the loads of k+3 into
+//     the same registers between the MFMAs of k; a batch has almost two k-steps to arrive;
+//   * the pure sign changes of A dY A^T (its last row and column) are left out of the loop and applied to the 7 affected
+//     components in the epilogue.
+// The four waves of a workgroup split the workgroup's pair range and add their accumulators through LDS; the first wave applies
+// G^T . G in-lane (all 16 components of a (co, ci) pair sit in one lane) and adds the 3 x 3 results into dw -- plain adds when the
+// range is not split over workgroups, float atomics otherwise; with a partial-sum workspace (deterministic mode) the workgroup
+// stores its 32 x 32 x 9 block there instead and wino_wgrad_reduce_kernel adds the blocks up in a fixed order.
 struct WinoWgradParams {
     const float* x;        // [B][H][W][Cin]
     const float* dy;       // [B][H][W][Cout]
     float* dw;             // [Cout][3][3][Cin], +=
     int B, H, W, Cin, Cout;
     int nblk_ci, nblk;     // 32-channel blocks of Cin; blocks of (Cout, Cin)
-    int S;                 // splits of the tile range over workgroups
-    int tiles_per_wg;      // multiple of 16
+    int S;                 // splits of the pair range over workgroups
+    int pairs_per_wg;      // multiple of 8 (four waves x an even number of k-steps)
     int CinW;              // row stride of dw in channels (= Cin, or the concatenated channel count when x is one of two sources)
     const float* yact;     // DACT: the forward output y [B][H][W][Cout]; dy is multiplied by act'(y) as it is loaded
     int dact;              // activation code of conv_common.h (1 ReLU, 2 ELU)
     float* dbias;          // DACT: null, or [Cout] += the column sums of dy act'(y) (taken by the workgroups of input-channel block 0)
+    float* part;           // null, or the partial-sum workspace [nblk][S][9][32][32] (ordered reduction instead of atomics)
 };
 
 // MODE 0: zero padding 1 (the BasicBlock layers).  The decoder's gathers (model/layers.py:26-41, model/depth_decoder.py:52-62):
-// MODE 1: ReflectionPad2d(1) -- a patch pixel outside the image moves two rows / columns back inside instead of reading zero (the
-//         same two vector operations per offset: an add instead of an or);  MODE 2: x is the half-resolution operand of the nearest
-//         2x upsample, [B][H/2][W/2][Cin] -- the 4 x 4 patch of output tile (ty, tx) is source pixels {ty-1, ty, ty, ty+1} x
-//         {tx-1, tx, tx, tx+1}, clamped at the border (= reflection of the upsampled image): 9 loads instead of 16.
+// MODE 1: ReflectionPad2d(1) -- a patch pixel outside the image moves two rows / columns back inside instead of reading zero;
+// MODE 2: x is the half-resolution operand of the nearest 2x upsample, [B][H/2][W/2][Cin] -- the 4 x 4 patch of output tile
+//         (ty, tx) is source pixels {ty-1, ty, ty, ty+1} x {tx-1, tx, tx, tx+1}, clamped at the border (= reflection of the
+//         upsampled image): 9 loads instead of 16.
 // The two sources of an upsample + concat layer are two launches, each adding into its own channel range of dw (CinW).
 // DACT (the thin decoder layers, whose gradient kernels apply the activation derivative themselves): dZ = dY act'(Y) is formed from
 // four more loads per tile and the bias gradient rides along.
 template <int MODE, bool DACT = false>
 __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
-    __shared__ float sR[2][256][64];                      // 128 KB: accumulators of two waves during the reduction
+    // 128 KB: in the loop the four waves' DMA rings (RING slots of NL x 64 floats each), afterwards the accumulators of two waves
+    // during the reduction.  ONE shared array: a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read.
+    __shared__ float sMem[2 * 256 * 64];
+    float (*const sR)[256][64] = reinterpret_cast<float (*)[256][64]>(sMem);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
-    const int TXn = (W + 1) >> 1, TYn = (H + 1) >> 1, ntiles = p.B * TYn * TXn;
-    // workgroups of one XCD walk the channel blocks of the same tile range first (its x / dY stay in that L2); with fewer than
-    // eight tile ranges (S = 1, 2 or 4) 8 / S XCDs share a range and deal its channel blocks between them
+    const int TXn = (W + 1) >> 1, TYn = (H + 1) >> 1, NP = (TXn + 1) >> 1, npairs = p.B * TYn * NP;
+    // workgroups of one XCD walk the channel blocks of the same pair range first (its x / dY stay in that L2); with fewer than
+    // eight ranges (S = 1, 2 or 4) 8 / S XCDs share a range and deal its channel blocks between them
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int blk, sp;
     if (p.S >= 8) {
@@ -545,121 +566,200 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     }
     if (sp >= p.S || blk >= p.nblk) return;
     const int co0 = (blk / p.nblk_ci) * 32, ci0 = (blk % p.nblk_ci) * 32;
-    const int per_wave = p.tiles_per_wg >> 2;              // multiple of 4: an even number of k-steps
-    const int t_begin = sp * p.tiles_per_wg + wave * per_wave;
-    const int t_end = min(t_begin + per_wave, ntiles);
-    const int ksteps = t_begin < ntiles ? per_wave >> 1 : 0;
+    const int per_wave = p.pairs_per_wg >> 2;              // even
+    const int q_begin = sp * p.pairs_per_wg + wave * per_wave;
+    const int nk = max(0, min(q_begin + per_wave, npairs) - q_begin);      // pairs (= k-steps) of this wave
 
-    // the x resource starts (W + 1) pixels before the tensor so that patch offsets are non-negative: pixel (i, j) of the patch of
-    // a tile whose first output pixel has index pb is at pb + (i - 1) W + (j - 1); reads in front of the tensor are masked out
-    constexpr int NX = MODE == 2 ? 9 : 16;                 // loads of one patch
+    constexpr int NC = MODE == 2 ? 3 : 4;                  // patch rows / columns that are loaded
+    constexpr int NX = NC * NC;
     constexpr int NY = DACT ? 8 : 4;                       // dY (and Y) values of one tile
     const int Hs = MODE == 2 ? H >> 1 : H, Ws = MODE == 2 ? W >> 1 : W;      // geometry of x
-    // MODE 1 / 2 move a mirrored / clamped pixel by up to two rows and two columns (one and one) towards the front: the resource starts
-    // that much earlier still and every offset carries the shift, so that voffset alone never goes below zero (the bounds check does
-    // not wrap)
-    const unsigned kshift = MODE == 1 ? 2u * (unsigned)((W + 1) * Cin * 4) : MODE == 2 ? (unsigned)((Ws + 1) * Cin * 4) : 0u;
-    const size_t lead = (size_t)(Ws + 1) * Cin * 4 + kshift;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)((size_t)p.B * Hs * Ws * Cin * 4 + lead), 0x00020000);
-    const __amdgpu_buffer_rsrc_t yr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DACT ? p.yact : p.dy), 0,
-                                                                        (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
-    constexpr unsigned OOB = 0xC0000000u;
+    const unsigned Cin4 = (unsigned)Cin * 4u, Cout4 = (unsigned)Cout * 4u;
+    // Addressing of one batch: address = resource base + soffset (scalar: the pair's origin) + voffset (per lane: channel, lane
+    // half, patch row and column) + the instruction's immediate (which only places the load's 256 bytes inside the LDS slot and is
+    // taken back out of the voffset).  x: the voffset counts patch rows from the row ABOVE the tile and columns from the column LEFT
+    // of the pair, so the resource starts one source row and one pixel in front of the tensor -- and another DLEAD bytes earlier for
+    // the immediates; what lies there is never read (row / column -1 are masked, mirrored or clamped).
+    constexpr unsigned DLEAD = 4096;
+    const size_t lead = (size_t)(Ws + 1) * Cin4 + DLEAD;
+    const unsigned xbytes = (unsigned)((size_t)p.B * Hs * Ws * Cin4 + lead), ybytes = (unsigned)((size_t)p.B * H * W * Cout4 + DLEAD);
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - lead, 0, (int)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.dy)) - DLEAD, 0, (int)ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(DACT ? p.yact : p.dy)) - DLEAD, 0, (int)ybytes, 0x00020000);
+    constexpr unsigned OOB_COL = 0x40000000u, OOB_ROW = 0x80000000u;      // marks of a masked column / row (see refresh)
     float bsum = 0.f;                                      // DACT: my channel's sum of dZ over my tiles
 
-    // my tile of k-step k: t_begin + 2 k + h
-    int t = t_begin + h, tb, ty, tx;
+    // ---- per-lane column offsets: middle pairs, the first pair of a tile row, the last one (also the first when NP == 1)
+    const unsigned chx = (unsigned)(ci0 + r) * 4u + DLEAD, chy = (unsigned)(co0 + r) * 4u + DLEAD;
+    unsigned vxM[NC], vxF0, vxL[NC], vyM[2], vyL[2];
     {
-        const int tc = min(t, ntiles - 1);
-        tb = tc / (TYn * TXn);
-        const int rem = tc - tb * (TYn * TXn);
-        ty = rem / TXn;
-        tx = rem - ty * TXn;
+        const int txl = 2 * (NP - 1) + h;                 // my tile in the last pair
+        const bool pad = txl >= TXn;                       // it does not exist (odd number of tiles per row)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            if constexpr (MODE == 2) {
+                vxM[j] = (unsigned)(h + j) * Cin4 + chx;   // source column tx - 1 + j, + 1
+                const int cc = min(max(txl - 1 + j, 0), Ws - 1);      // clamped (a pad tile lands on the last column: finite)
+                vxL[j] = (unsigned)(cc - 2 * (NP - 1) + 1) * Cin4 + chx;
+            } else {
+                vxM[j] = (unsigned)(2 * h + j) * Cin4 + chx;   // image column 2 tx - 1 + j, + 1
+                const int c = 2 * txl - 1 + j;
+                if constexpr (MODE == 0) {
+                    vxL[j] = vxM[j] | ((pad || c >= W || c < 0) ? OOB_COL : 0u);
+                } else {
+                    // mirrored column; a pad tile repeats the columns of its (real) left neighbour: its dY is masked, its x only has
+                    // to be finite
+                    const int c0 = pad ? c - 2 : c;
+                    // (column W + 1 only meets a masked dY column: any finite value does, it stays right of the pair's origin - 1)
+                    const int cm = max(c0 < 0 ? -c0 : c0 >= W ? 2 * (W - 1) - c0 : c0, 4 * (NP - 1) - 1);
+                    vxL[j] = (unsigned)(cm - 4 * (NP - 1) + 1) * Cin4 + chx;
+                }
+            }
+        }
+        if constexpr (MODE == 0) vxF0 = vxM[0] | (h == 0 ? OOB_COL : 0u);
+        else vxF0 = vxM[0] + (h == 0 ? (MODE == 1 ? 2u : 1u) * Cin4 : 0u);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            vyM[b] = (unsigned)(2 * h + b) * Cout4 + chy;
+            vyL[b] = vyM[b] | ((pad || 2 * txl + b >= W) ? OOB_COL : 0u);
+        }
     }
-    // offsets of the current tile's 16 (9) + 4 loads: v | row mask | column mask, a mask being 0 (inside) or OOB (outside: the OR
-    // lands beyond every tensor < 2 GiB); then two tiles on
-    unsigned ox_[NX], oy_[4];
-    auto offsets_and_advance = [&]() {
-        const int oy = 2 * ty, ox = 2 * tx;
-        const unsigned pb = (unsigned)((tb * H + oy) * W + ox);
-        const unsigned vy = (pb * Cout + co0 + r) * 4u;
-        const unsigned dead = t < t_end ? 0u : OOB;
-        if constexpr (MODE == 0) {
-            const unsigned vx = (pb * Cin + ci0 + r) * 4u;
-            const unsigned rm[4] = {oy >= 1 ? dead : OOB, dead, oy + 1 < H ? dead : OOB, oy + 2 < H ? dead : OOB};
-            const unsigned cm[4] = {ox >= 1 ? 0u : OOB, 0u, ox + 1 < W ? 0u : OOB, ox + 2 < W ? 0u : OOB};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ox_[4 * i + j] = vx | rm[i] | cm[j];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) oy_[2 * i + j] = vy | rm[1 + i] | cm[1 + j];
-        } else if constexpr (MODE == 1) {
-            // rows oy - 1 .. oy + 2: -1 -> 1, H -> H - 2 (with H odd the last tile row has oy + 1 == H: its first output row reads
-            // that mirrored row); row H + 1 only meets the masked second dY row of such a tile: it reads zero.  Columns alike.
-            const unsigned vx = (pb * Cin + ci0 + r) * 4u + kshift;
-            const unsigned rowb = (unsigned)(W * Cin * 4), colb = (unsigned)(Cin * 4);
-            const unsigned in_r = oy + 1 < H ? dead : OOB, in_c = ox + 1 < W ? 0u : OOB;
-            const unsigned rm[4] = {dead, dead, dead, in_r};
-            const unsigned cm[4] = {0u, 0u, 0u, in_c};
-            const unsigned vr[4] = {vx + (oy >= 1 ? 0u : 2u * rowb), vx, vx - (oy + 1 == H ? 2u * rowb : 0u), vx - (oy + 2 == H ? 2u * rowb : 0u)};
-            const unsigned ca[4] = {ox >= 1 ? 0u : 2u * colb, 0u, ox + 1 == W ? 0u - 2u * colb : 0u, ox + 2 == W ? 0u - 2u * colb : 0u};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ox_[4 * i + j] = (vr[i] + ca[j]) | rm[i] | cm[j];
-            oy_[0] = vy | dead;
-            oy_[1] = vy | dead | in_c;
-            oy_[2] = vy | in_r;
-            oy_[3] = vy | in_r | in_c;
-        } else {
-            // source pixel (ty, tx) and its eight neighbours, clamped (H and W are even: every tile is whole)
-            const unsigned vs = (unsigned)((((tb * Hs + ty) * Ws + tx) * Cin + ci0 + r) * 4) + kshift;
-            const unsigned rowb = (unsigned)(Ws * Cin * 4), colb = (unsigned)(Cin * 4);
-            const unsigned vr[3] = {vs + (ty >= 1 ? 0u : rowb), vs, vs - (ty + 1 < Hs ? 0u : rowb)};
-            const unsigned ca[3] = {tx >= 1 ? 0u : colb, 0u, tx + 1 < Ws ? 0u : 0u - colb};
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ox_[3 * i + j] = (vr[i] + ca[j]) | dead;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oy_[e] = vy | dead;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            ++tx;
-            const bool wx = tx == TXn;
-            tx = wx ? 0 : tx;
-            ty += wx ? 1 : 0;
-            const bool wy = ty == TYn;
-            ty = wy ? 0 : ty;
-            tb += wy ? 1 : 0;
-        }
-        t += 2;
+
+    // ---- the wave's position: pair q = (tb, ty, txp); everything about it is wave-uniform (scalar unit)
+    int tb, ty, txp;
+    {
+        const int q = min(q_begin, max(npairs - 1, 0));
+        tb = q / (TYn * NP);
+        const int rem = q - tb * (TYn * NP);
+        ty = rem / NP;
+        txp = rem - ty * NP;
+        // the divisions are expanded on the vector unit; without these the whole scalar chain below follows them into VGPRs and
+        // every buffer load is wrapped in a waterfall loop
+        tb = __builtin_amdgcn_readfirstlane(tb);
+        ty = __builtin_amdgcn_readfirstlane(ty);
+        txp = __builtin_amdgcn_readfirstlane(txp);
+    }
+    // The fp32 MFMA holds the wave's issue for its 64 cycles (counters: MFMA + vector + scalar + memory issue cycles of a wave ADD
+    // UP to its run time at one wave per SIMD), so what counts is the NUMBER of instructions per k-step, of any kind.  The offsets of a
+    // batch therefore live in registers that only change where the pair's class changes:
+    //   cvx[i][j], cvy[a][b] -- the voffsets of the 16 (9) + 4 loads: column variant + row offset, or OOB for a row that must read
+    //   zeros (above / below the image, a k-step past the wave's range); rewritten when the wave enters a tile row (all), leaves its
+    //   first pair (column 0) or enters its last pair (all: a handful of k-steps per tile row), in branches the other k-steps skip;
+    //   sxb, syb -- the soffsets (the pair's origin): one scalar add each per k-step.
+    unsigned cvx[NC][NC], cvy[2][2], sxb = 0, syb = 0;
+    int kq = 0;                                            // k-step (of this wave) at (tb, ty, txp)
+    auto origin = [&]() __attribute__((always_inline)) {
+        if constexpr (MODE == 2) sxb = (unsigned)((tb * Hs + ty) * Ws + 2 * txp) * Cin4;
+        else sxb = (unsigned)((tb * H + 2 * ty) * W + 4 * txp) * Cin4;
+        syb = (unsigned)((tb * H + 2 * ty) * W + 4 * txp) * Cout4;
     };
-    // one batch = the 4 (8) dY (and Y) values of my tile, then its 16 (9) patch pixels; the staging moves (stage_loaded) read them in
-    // the same order, so the waits in front of those moves count down through the batch
-    auto issue_loads = [&](float (&xd)[NX], float (&yd)[NY]) {
+    // columns [J0, J1) of cvx (and, with WITH_Y, cvy) for the pair at (ty, txp).  A value is (column variant: per lane) + (row term:
+    // scalar).  Masked columns carry OOB_COL, masked rows add OOB_ROW: with offsets below 2^30 (the launcher checks the tensors) no sum
+    // wraps, and every marked sum lies beyond the resource's records: the load returns 0.
+    auto refresh = [&](auto j0_tag, auto j1_tag, auto y_tag) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
+        constexpr bool WITH_Y = decltype(y_tag)::value;
+        const bool live = kq < nk, first = txp == 0, last = txp == NP - 1;
+        const int oy = 2 * ty;
+        unsigned col[NC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            yd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
-        if constexpr (DACT) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                yd[4 + e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ar, oy_[e], ((e >> 1) * W + (e & 1)) * Cout * 4, 0));
+        for (int j = J0; j < J1; ++j) {
+            const unsigned m = vxM[j], l = vxL[j], f = vxF0;      // values first, then the selects: a ?: over the captured variables
+            col[j] = last ? l : (j == 0 && first) ? f : m;        // themselves selects between their ADDRESSES inside the closure
         }
 #pragma unroll
-        for (int e = 0; e < NX; ++e) {
-            const int soff = MODE == 2 ? ((e / 3) * Ws + (e % 3)) * Cin * 4 : ((e >> 2) * W + (e & 3)) * Cin * 4;
-            xd[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ox_[e], soff, 0));
+        for (int i = 0; i < NC; ++i) {
+            // patch row i: its distance (in source rows) from the row above the tile, or the mark of a row that reads zeros
+            int rofs;
+            bool ok = live;
+            if constexpr (MODE == 0) {
+                rofs = i;
+                ok = ok & (oy - 1 + i >= 0) & (oy - 1 + i < H);
+            } else if constexpr (MODE == 1) {
+                const int rw = oy - 1 + i, rm = max(rw < 0 ? -rw : rw >= H ? 2 * (H - 1) - rw : rw, 0);
+                rofs = rm - (oy - 1);
+            } else {
+                rofs = min(max(ty - 1 + i, 0), Hs - 1) - (ty - 1);
+            }
+            const unsigned rterm = ((unsigned)(rofs * Ws) * Cin4) | (OOB_ROW & (0u - (unsigned)!ok));
+#pragma unroll
+            for (int j = J0; j < J1; ++j) cvx[i][j] = col[j] + (rterm - (unsigned)((i * NC + j) * 256));
+        }
+        if constexpr (WITH_Y) {
+            unsigned cy[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const unsigned m = vyM[b], l = vyL[b];
+                cy[b] = last ? l : m;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bool ok = live & (oy + a < H);
+                const unsigned rterm = ((unsigned)(a * W) * Cout4) | (OOB_ROW & (0u - (unsigned)!ok));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) cvy[a][b] = cy[b] + (rterm - (unsigned)((2 * a + b) * 256));
+            }
         }
     };
-    auto transform = [&](const float (&xs)[NX], const float (&yl)[NY], float (&v)[16], float (&pm)[16]) {
-        float tt[4][4], pr[4][2], xc[16], yc[4];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IN = std::integral_constant<int, NC>;
+    // to the next pair (an interior k-step: four scalar adds and the compares that fall through)
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++kq;
+        ++txp;
+        sxb += (MODE == 2 ? 2u : 4u) * Cin4;
+        syb += 4u * Cout4;
+        if (txp == NP) {
+            txp = 0;
+            ++ty;
+            if (ty == TYn) {
+                ty = 0;
+                ++tb;
+            }
+            origin();
+        }
+        if (txp == 0 || txp == NP - 1 || kq == nk || NP <= 2) refresh(I0{}, IN{}, std::true_type{});      // entering a row / its last pair
+        else if (txp == 1) refresh(I0{}, I1{}, std::false_type{});                                          // leaving the first pair
+    };
+
+    // One batch = the 4 (8) dY (and Y) values of my tile, then its 16 (9) patch pixels, as LDS-DMA loads (buffer_load_dword ... lds:
+    // 64 lanes x 4 bytes land lane-linear at M0 + immediate): nothing in flight occupies a register, so no loop-carried register
+    // set exists for the allocator to copy around (round 2's kernel paid 20 staging moves per k-step to keep its in-flight
+    // registers fixed; left to itself the allocator put such copies -- behind a vmcnt(0) -- at the loop's back edge).  The loads of a
+    // group share one M0 (the slot's base); the immediate that separates them is taken back out of the voffsets (refresh).
+    constexpr int NL = NX + NY, RING = 4;                  // loads per k-step; ring slots = prefetch distance (3 k-steps) + 1
+    float* const ring = sMem + wave * (RING * NL * 64);
+    using lds_t = __attribute__((address_space(3))) void*;
+    auto issue_dma = [&](int slot) __attribute__((always_inline)) {
+        float* const dst = ring + slot * (NL * 64);
+#define WINO_DMA_Y(A, B2)                                                                                                       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_t)dst, 4, cvy[A][B2], syb, (2 * A + B2) * 256, 0);                          \
+    if constexpr (DACT) __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_t)(dst + 4 * 64), 4, cvy[A][B2], syb, (2 * A + B2) * 256, 0);
+        WINO_DMA_Y(0, 0) WINO_DMA_Y(0, 1) WINO_DMA_Y(1, 0) WINO_DMA_Y(1, 1)
+#undef WINO_DMA_Y
+#define WINO_DMA_X(I, J) \
+    if constexpr (I < NC && J < NC) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_t)(dst + NY * 64), 4, cvx[I][J], sxb, (I * NC + J) * 256, 0);
+#define WINO_DMA_XROW(I) WINO_DMA_X(I, 0) WINO_DMA_X(I, 1) WINO_DMA_X(I, 2) WINO_DMA_X(I, 3)
+        WINO_DMA_XROW(0) WINO_DMA_XROW(1) WINO_DMA_XROW(2) WINO_DMA_XROW(3)
+#undef WINO_DMA_XROW
+#undef WINO_DMA_X
+    };
+    // (the lane's read address of the NEXT k-step is formed behind the transform, so that the LDS reads depend on nothing inside the
+    // MFMA block they are issued in)
+    auto read_slot = [&](const float* src, float (&xv)[NX], float (&yv)[NY]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < NY; ++e) yv[e] = src[e * 64];
+#pragma unroll
+        for (int e = 0; e < NX; ++e) xv[e] = src[(NY + e) * 64];
+    };
+    // v = B^T d B;  pm = |A| dY |A|^T: rows (1,0), (1,1), (1,-1), (0,1) -- the true A has (0,-1) as its last row, i.e. components
+    // (3, l) and (i, 3) carry a factor -1 each that the epilogue applies (kWgradSign)
+    auto transform = [&](const float (&xs)[NX], const float (&yl)[NY], float (&v)[16], float (&pm)[16]) __attribute__((always_inline)) {
+        float tt[4][4], xc[16], yc[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             yc[e] = yl[e];
@@ -688,19 +788,14 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             v[4 * i + 2] = tt[i][2] - tt[i][1];
             v[4 * i + 3] = tt[i][1] - tt[i][3];
         }
+        // |A| dY: rows y0, y0 + y1, y0 - y1, y1 (per column j); then the same along the columns
+        const float pr[4][2] = {{yc[0], yc[1]}, {yc[0] + yc[2], yc[1] + yc[3]}, {yc[0] - yc[2], yc[1] - yc[3]}, {yc[2], yc[3]}};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {                     // A dY: rows (1,0), (1,1), (1,-1), (0,-1)
-            pr[0][j] = yc[j];
-            pr[1][j] = yc[j] + yc[2 + j];
-            pr[2][j] = yc[j] - yc[2 + j];
-            pr[3][j] = -yc[2 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                     // (A dY) A^T
+        for (int i = 0; i < 4; ++i) {
             pm[4 * i + 0] = pr[i][0];
             pm[4 * i + 1] = pr[i][0] + pr[i][1];
             pm[4 * i + 2] = pr[i][0] - pr[i][1];
-            pm[4 * i + 3] = -pr[i][1];
+            pm[4 * i + 3] = pr[i][1];
         }
     };
 
@@ -710,55 +805,60 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
-    // step k: the values loaded during step k-1 (k-step k+1's) move from the in-flight set rl to the staging set sn -- real moves,
-    // placed where the transform needs the data anyway; the loads of k+2 -> rl (its offsets were computed in step k-1); MFMAs from
-    // (vc, pc); (vn, pn) <- transform of sn.  With two alternating load sets the register allocator carried a few loaded values
-    // around the loop in other registers and put the copies -- hence an s_waitcnt for the batch issued in that very k-step -- at the
-    // back edge: every second k-step ran without any prefetch distance.
-    // Two in-flight sets (ra, rb) alternate, so a batch has TWO k-steps (~0.9 us) to arrive: it is issued in step k and staged in
-    // step k + 2.
-    float rax[NX], ray[NY], rbx[NX], rby[NY], snx[NX], sny[NY], v0[16], p0[16], v1[16], p1[16];
-    auto stage_loaded = [&](const float (&lx)[NX], const float (&ly)[NY]) {
+    // Step k:  DMA of k-step k+3 -> the slot that held k-1 (read and transformed during step k-2)  |  the first MFMAs of k  |  wait
+    // until the batch of k+1 has landed (two younger batches stay in flight)  |  its 20 values LDS -> registers  |  the other MFMAs  |
+    // transform of k+1 into the operand registers the MFMAs have just read.
+    float tx[NX], ty_[NY], v[16], pm[16];
+#define WINO_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    origin();
+    refresh(I0{}, IN{}, std::true_type{});
+    int slot_w = 0;                                        // slot the next batch goes to
 #pragma unroll
-        for (int e = 0; e < NY; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sny[e]) : "v"(ly[e]));
+    for (int j = 0; j < RING - 1; ++j) {                   // k-steps 0, 1, 2
+        if (j) advance();
+        issue_dma(slot_w);
+        slot_w = (slot_w + 1) & (RING - 1);
+    }
+    WINO_WAIT_VMCNT((RING - 2) * NL);                      // k-step 0 has landed
+    read_slot(ring + lane, tx, ty_);
+    transform(tx, ty_, v, pm);
+    int slot_r = 1;                                        // slot of k-step k+1
+    const float* rd = ring + slot_r * (NL * 64) + lane;
+    for (int k = 0; k < nk; ++k) {
+        advance();                                         // (at the head of the step: behind the transform the compiler sank the
+        __builtin_amdgcn_sched_barrier(0);                 // transform -- and with it the LDS reads -- below advance's branches)
+        issue_dma(slot_w);
 #pragma unroll
-        for (int e = 0; e < NX; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(snx[e]) : "v"(lx[e]));
-    };
-    // step k: k-step k+1's values (loaded during step k-2) -> sn; loads of k+3 -> the same set; (vn, pn) <- transform of sn; offsets
-    // of k+4; MFMAs from (vc, pc)
-    auto kstep = [&](float (&lx)[NX], float (&ly)[NY], const float (&vc)[16], const float (&pc)[16], float (&vn)[16], float (&pn)[16]) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_loaded(lx, ly);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_loads(lx, ly);
-        __builtin_amdgcn_sched_barrier(0);
-        transform(snx, sny, vn, pn);
-        offsets_and_advance();
+        for (int q = 0; q < 6; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pm[q], v[q], acc[q], 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pc[q], vc[q], acc[q], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);     // VALU
+            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);     // VMEM read (the DMAs)
         }
-    };
-    offsets_and_advance();
-    issue_loads(rax, ray);                                // k-step 0
-    offsets_and_advance();
-    issue_loads(rbx, rby);                                // k-step 1
-    offsets_and_advance();
-    stage_loaded(rax, ray);
-    issue_loads(rax, ray);                                // k-step 2
-    offsets_and_advance();                                // offsets of k-step 3
-    transform(snx, sny, v0, p0);
-    for (int k = 0; k < ksteps; k += 2) {
-        kstep(rbx, rby, v0, p0, v1, p1);
-        kstep(rax, ray, v1, p1, v0, p0);
+        __builtin_amdgcn_sched_barrier(0);
+        WINO_WAIT_VMCNT((RING - 2) * NL);
+        read_slot(rd, tx, ty_);
+#pragma unroll
+        for (int q = 6; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pm[q], v[q], acc[q], 0, 0, 0);
+#pragma unroll
+        for (int i = 6; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        transform(tx, ty_, v, pm);
+        slot_w = (slot_w + 1) & (RING - 1);
+        slot_r = (slot_r + 1) & (RING - 1);
+        rd = ring + slot_r * (NL * 64) + lane;
     }
     __builtin_amdgcn_sched_barrier(0);
+    WINO_WAIT_VMCNT(0);                                    // the batches past the end (they read zeros) must not land in sR
+#undef WINO_WAIT_VMCNT
+    __syncthreads();                                       // every wave is done with its ring: the reduction may overwrite it
 
     if constexpr (DACT) {
         // every tile's dZ went through transform() exactly once per (output-channel, input-channel) block: block column 0 reports
+        // (the batches loaded beyond the wave's last k-step read zeros: dead k-steps have no records)
         if (p.dbias && ci0 == 0) {
             const float b2 = bsum + __shfl_xor(bsum, 32, 64);
             if (h == 0) atomicAdd(p.dbias + co0 + r, b2);
@@ -788,12 +888,16 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     __syncthreads();
     if (wave == 0) {
         const bool exclusive = p.S == 1;                  // this workgroup alone owns its block of dw
+        float* const part = p.part ? p.part + ((size_t)blk * p.S + sp) * (9 * 1024) : nullptr;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;  // output channel row of the block
             float u[4][4], t3[3][4];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) u[q >> 2][q & 3] = acc[q][i] + sR[0][q * 16 + i][lane];
+            for (int q = 0; q < 16; ++q) {
+                const float s = acc[q][i] + sR[0][q * 16 + i][lane];
+                u[q >> 2][q & 3] = ((q >> 2) == 3) != ((q & 3) == 3) ? -s : s;     // the signs left out of the loop's dY transform
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {                  // G^T dU
                 const float hs = 0.5f * (u[1][b] + u[2][b]);
@@ -808,6 +912,10 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
                 const float w3[3] = {t3[k][0] + hs, 0.5f * (t3[k][1] - t3[k][2]), hs + t3[k][3]};
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
+                    if (part) {
+                        part[((3 * k + l) * 32 + m) * 32 + r] = w3[l];
+                        continue;
+                    }
                     float* a = o + (size_t)(3 * k + l) * p.CinW;
                     if (exclusive) *a += w3[l];
                     else atomicAdd(a, w3[l]);
@@ -815,6 +923,19 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             }
         }
     }
+}
+
+// Ordered second pass of the deterministic weight gradient: dw[co][tap][ci] += sum over the S partial blocks, in split order.
+// One thread per element of a (32 x 32 x 9) block; grid = nblk * 9 * 4 workgroups of 256.
+__global__ __launch_bounds__(NT) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk_ci, int S,
+                                                               int CinW) {
+    const int blk = blockIdx.x / 36, e = (blockIdx.x % 36) * NT + threadIdx.x;      // e = (tap * 32 + m) * 32 + r
+    const int tap = e >> 10, m = (e >> 5) & 31, r = e & 31;
+    const float* src = part + (size_t)blk * S * (9 * 1024) + e;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += src[(size_t)i * (9 * 1024)];
+    const int co = (blk / nblk_ci) * 32 + m, ci = (blk % nblk_ci) * 32 + r;
+    dw[((size_t)co * 9 + tap) * CinW + ci] += s;
 }
 
 template <int WT, int WC, int GEN = 0>
@@ -843,27 +964,41 @@ void launch_wino(WinoParams& p, hipStream_t st) {
 }
 
 // x: the source tensor of this launch (MODE 2: at half resolution); dw: already offset to the source's first channel, CinW its row stride
-template <int MODE, bool DACT = false>
-void launch_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int CinW, int target_workgroups,
-                       hipStream_t st, const float* yact = nullptr, int dact = 0, float* dbias = nullptr) {
-    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0, CinW, yact, dact, dbias};
-    const int ntiles = B * ((H + 1) / 2) * ((W + 1) / 2);
-    // default: one round of one workgroup per CU (fewer, longer tile ranges: less reduction and atomic traffic); the 512-channel
-    // layers take two tile ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
-    if (target_workgroups <= 0) target_workgroups = p.nblk >= 256 ? 512 : 256;
-    int S = (target_workgroups + p.nblk / 2) / p.nblk;
+// pair ranges of one launch: S splits of pairs_per_wg tile pairs each (pairs of a tile row padded to an even tile count)
+struct WgradSplit {
+    int S, ppw;
+};
+inline WgradSplit wino_wgrad_split(int B, int H, int W, int Cin, int Cout, int target_workgroups) {
+    const int nblk = (Cin / 32) * (Cout / 32);
+    const int TXn = (W + 1) / 2, TYn = (H + 1) / 2, NP = (TXn + 1) / 2, npairs = B * TYn * NP;
+    // default: one round of one workgroup per CU (fewer, longer ranges: less reduction and atomic traffic); the 512-channel
+    // layers take two ranges so that one XCD's share of x and dY fits its L2 (measured: profiles/r02_f_wino_wgrad_split.txt)
+    if (target_workgroups <= 0) target_workgroups = nblk >= 256 ? 512 : 256;
+    int S = (target_workgroups + nblk / 2) / nblk;
     S = S < 1 ? 1 : S;
-    int tpw = ((ntiles + S - 1) / S + 15) & ~15;          // tiles per workgroup: four waves x two tiles x an even number of k-steps
-    tpw = tpw < 64 ? 64 : tpw;                             // at least eight k-steps per wave
-    S = (ntiles + tpw - 1) / tpw;
+    int ppw = ((npairs + S - 1) / S + 7) & ~7;            // pairs per workgroup: four waves x an even number of k-steps
+    ppw = ppw < 32 ? 32 : ppw;                             // at least eight k-steps per wave
+    S = (npairs + ppw - 1) / ppw;
     if (S < 8) {                                           // 1, 2 or 4 ranges (the XCD map of the kernel); ranges past the end add zeros
         S = S >= 4 ? 4 : S >= 2 ? 2 : 1;
-        tpw = ((ntiles + S - 1) / S + 15) & ~15;
+        ppw = ((npairs + S - 1) / S + 7) & ~7;
     }
-    p.tiles_per_wg = tpw;
-    p.S = S;
+    return {S, ppw};
+}
+
+// x: the source tensor of this launch (MODE 2: at half resolution); dw: already offset to the source's first channel, CinW its row stride
+template <int MODE, bool DACT = false>
+void launch_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int CinW, int target_workgroups,
+                       hipStream_t st, const float* yact = nullptr, int dact = 0, float* dbias = nullptr, float* part = nullptr) {
+    WinoWgradParams p{x, dy, dw, B, H, W, Cin, Cout, Cin / 32, (Cin / 32) * (Cout / 32), 0, 0, CinW, yact, dact, dbias, part};
+    const WgradSplit sp = wino_wgrad_split(B, H, W, Cin, Cout, target_workgroups);
+    p.pairs_per_wg = sp.ppw;
+    p.S = sp.S;
+    const int S = sp.S;
     const size_t grid = S >= 8 ? (size_t)((S + 7) / 8) * 8 * p.nblk : (size_t)((p.nblk + 8 / S - 1) / (8 / S)) * 8;
     hipLaunchKernelGGL((wino_wgrad_kernel<MODE, DACT>), dim3((unsigned)grid), dim3(NT), 0, st, p);
+    if (part)
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(p.nblk * 36)), dim3(NT), 0, st, part, dw, p.nblk_ci, S, CinW);
 }
 
 }  // namespace
@@ -939,22 +1074,36 @@ int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const 
     return dvs::check_launch("dvs_conv3x3_wino_gen");
 }
 
-int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
-                           void* stream) {
+size_t dvs_conv3x3_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int target_workgroups) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32) return 0;
+    const WgradSplit sp = wino_wgrad_split(B, H, W, Cin, Cout, target_workgroups);
+    return (size_t)(Cin / 32) * (Cout / 32) * sp.S * 9 * 1024 * sizeof(float);
+}
+
+int dvs_conv3x3_wino_wgrad_ws(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
+                              float* workspace, size_t workspace_bytes, void* stream) {
     DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0, "dvs_conv3x3_wino_wgrad: bad argument");
     DVS_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_wino_wgrad: channel counts must be multiples of 32 (got %d, %d)",
                 Cin, Cout);
-    DVS_REQUIRE(((double)B * H * W + W + 1) * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0,
-                "dvs_conv3x3_wino_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    DVS_REQUIRE(((double)B * H * W + W + 1) * (Cin > Cout ? Cin : Cout) * 4 + 8192 < 1073741824.0,
+                "dvs_conv3x3_wino_wgrad: tensors must be smaller than 1 GiB (32-bit buffer offsets with two mask bits)");
+    DVS_REQUIRE(!workspace || workspace_bytes >= dvs_conv3x3_wino_wgrad_workspace(B, H, W, Cin, Cout, target_workgroups),
+                "dvs_conv3x3_wino_wgrad_ws: workspace of %zu bytes is too small", workspace_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
     prof.work(2.0 * B * H * W * Cout * (double)Cin * 9);
-    launch_wino_wgrad<0>(x, dy, dw, B, H, W, Cin, Cout, Cin, target_workgroups, st);
+    launch_wino_wgrad<0>(x, dy, dw, B, H, W, Cin, Cout, Cin, target_workgroups, st, nullptr, 0, nullptr, workspace);
     return dvs::check_launch("dvs_conv3x3_wino_wgrad");
 }
 
-int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
-                               int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, void* stream) {
+int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
+                           void* stream) {
+    return dvs_conv3x3_wino_wgrad_ws(x, dy, dw, B, H, W, Cin, Cout, target_workgroups, nullptr, 0, stream);
+}
+
+int dvs_conv3x3_wino_wgrad_gen_ws(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H,
+                                  int W, int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, float* workspace,
+                                  size_t workspace_bytes, void* stream) {
     DVS_REQUIRE(x && dy && dw && B > 0 && H >= 2 && W >= 2, "dvs_conv3x3_wino_wgrad_gen: bad argument (ReflectionPad2d(1) needs H, W >= 2)");
     DVS_REQUIRE((C2 == 0) == (x2 == nullptr) && C2 >= 0, "dvs_conv3x3_wino_wgrad_gen: x2 and C2 go together");
     DVS_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 % 32 == 0 && Cout > 0 && Cout % 32 == 0,
@@ -965,22 +1114,31 @@ int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy,
                 "dvs_conv3x3_wino_wgrad_gen: activation %d (0, 1 = ReLU, 2 = ELU; with the forward output)", dact);
     DVS_REQUIRE(!dbias || dact, "dvs_conv3x3_wino_wgrad_gen: the bias gradient rides on the activation-derivative path (dact != 0)");
     const int cmax = (C1 > C2 ? C1 : C2) > Cout ? (C1 > C2 ? C1 : C2) : Cout;
-    DVS_REQUIRE(((double)B * H * W + 3 * W + 3) * cmax * 4 < 2147483648.0,
-                "dvs_conv3x3_wino_wgrad_gen: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    DVS_REQUIRE(((double)B * H * W + 3 * W + 3) * cmax * 4 + 8192 < 1073741824.0,
+                "dvs_conv3x3_wino_wgrad_gen: tensors must be smaller than 1 GiB (32-bit buffer offsets with two mask bits)");
+    DVS_REQUIRE(!workspace || workspace_bytes >= dvs_conv3x3_wino_wgrad_workspace(B, H, W, C1 > C2 ? C1 : C2, Cout, target_workgroups),
+                "dvs_conv3x3_wino_wgrad_gen_ws: workspace of %zu bytes is too small", workspace_bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);       // flops of the direct weight gradient
     prof.work(2.0 * B * H * W * Cout * (double)(C1 + C2) * 9);
     const int Ct = C1 + C2, tw = target_workgroups;
+    float* const ws = workspace;                           // the two sources' launches run one after the other on `st`: one workspace
     if (dact) {
-        if (upsample) launch_wino_wgrad<2, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias);
-        else launch_wino_wgrad<1, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias);
-        if (C2) launch_wino_wgrad<1, true>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st, y_out, dact, nullptr);
+        if (upsample) launch_wino_wgrad<2, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias, ws);
+        else launch_wino_wgrad<1, true>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, y_out, dact, dbias, ws);
+        if (C2) launch_wino_wgrad<1, true>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st, y_out, dact, nullptr, ws);
     } else {
-        if (upsample) launch_wino_wgrad<2>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st);
-        else launch_wino_wgrad<1>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st);
-        if (C2) launch_wino_wgrad<1>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st);
+        if (upsample) launch_wino_wgrad<2>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, nullptr, 0, nullptr, ws);
+        else launch_wino_wgrad<1>(x, dy, dw, B, H, W, C1, Cout, Ct, tw, st, nullptr, 0, nullptr, ws);
+        if (C2) launch_wino_wgrad<1>(x2, dy, dw + C1, B, H, W, C2, Cout, Ct, tw, st, nullptr, 0, nullptr, ws);
     }
     return dvs::check_launch("dvs_conv3x3_wino_wgrad_gen");
+}
+
+int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
+                               int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, void* stream) {
+    return dvs_conv3x3_wino_wgrad_gen_ws(x, x2, dy, y_out, dw, dbias, B, H, W, C1, C2, Cout, upsample, dact, target_workgroups, nullptr, 0,
+                                         stream);
 }
 
 }  // extern "C"

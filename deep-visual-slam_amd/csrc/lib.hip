@@ -91,6 +91,30 @@ void prof_end(int slot, hipStream_t st, hipEvent_t start, double work) {
 
 }  // namespace dvs
 
+
+// ------------------------------------------------------------------ on-box peak probes (bench.py: `measured_peaks`)
+namespace {
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+// one wave per SIMD on every CU, four independent accumulators, operands in registers: the fp32 matrix rate a kernel can reach
+__global__ __launch_bounds__(256, 1) void mfma_probe_kernel(float* out, int iters) {
+    f32x16_t a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    float x = 1.0f + (float)threadIdx.x * 1e-3f, y = 0.5f - (float)threadIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i] + a2[i] + a3[i];
+    if (s == 12345.678f) out[0] = s;                      // never true: keeps the loop alive
+}
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" {
 
 int dvs_profile_enable(int on) {
@@ -141,8 +165,24 @@ int dvs_set_deterministic(int on) {
 
 int dvs_get_deterministic(void) { return dvs::deterministic() ? 1 : 0; }
 
-int dvs_abi_version(void) { return 6; }
+int dvs_abi_version(void) { return 7; }
 
 const char* dvs_arch(void) { return "gfx950"; }
+
+int dvs_peak_probe_mfma(float* scratch, int iters, double* flops, void* stream) {
+    DVS_REQUIRE(scratch && iters > 0 && flops, "dvs_peak_probe_mfma: bad argument");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3((unsigned)cus), dim3(256), 0, static_cast<hipStream_t>(stream), scratch, iters);
+    *flops = 2.0 * 32 * 32 * 2 * 4.0 * iters * 4.0 * cus;  // 4 MFMAs per iteration, 4 waves per workgroup
+    return dvs::check_launch("dvs_peak_probe_mfma");
+}
+
+int dvs_peak_probe_copy(const void* src, void* dst, size_t bytes, void* stream) {
+    DVS_REQUIRE(src && dst && bytes >= 16 && (bytes & 15) == 0, "dvs_peak_probe_copy: bad argument");
+    hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float4*>(src),
+                       static_cast<float4*>(dst), bytes / 16);
+    return dvs::check_launch("dvs_peak_probe_copy");
+}
 
 }  // extern "C"

@@ -102,7 +102,9 @@ class RcclComm:
             _rccl.check(l.dvs_allreduce_unique_id(buf), "dvs_allreduce_unique_id")
             token[0] = bytes(buf)
         if self.world > 1:
-            dist.broadcast_object_list(token, src=0, group=group)
+            # `src` is a GLOBAL rank: with a sub-group the group's rank 0 is not rank 0 of the world
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(token, src=src, group=group)
         self.device = torch.device(device)
         with torch.cuda.device(self.device):
             handle = C.c_void_p()
@@ -119,6 +121,21 @@ class RcclComm:
         self._rccl.check(self._rccl.lib().dvs_allreduce_run(self.handle, tensor.data_ptr(), tensor.numel(), self.stream.cuda_stream),
                          "dvs_allreduce_run")
         tensor.record_stream(self.stream)
+
+    def all_reduce_ranges_(self, base, ranges):
+        """In-place sum of several element ranges [(start, end), ...] of `base` as ONE RCCL group (one launch:
+        dvs_allreduce_run_ranges), enqueued on self.stream after everything the current stream has enqueued."""
+        if not (base.is_cuda and base.is_contiguous() and base.dtype == torch.float32):
+            raise _lib.DvsError("RcclComm.all_reduce_ranges_: contiguous fp32 GPU tensor expected")
+        n = len(ranges)
+        if n == 0:
+            return
+        offs = (C.c_size_t * n)(*[int(s) for s, _ in ranges])
+        cnts = (C.c_size_t * n)(*[int(e - s) for s, e in ranges])
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._rccl.check(self._rccl.lib().dvs_allreduce_run_ranges(self.handle, base.data_ptr(), offs, cnts, n, self.stream.cuda_stream),
+                         "dvs_allreduce_run_ranges")
+        base.record_stream(self.stream)
 
     def wait(self):
         """The current stream waits for every all-reduce enqueued so far."""
@@ -189,6 +206,16 @@ class GradSync:
         self.sizes = [0] * len(self.buckets)
         for b in self.bucket_of:
             self.sizes[b] += 1
+        # The tail bucket of each network (its stem: complete only when the backward pass is) is not reduced from its hook but
+        # in finish(), together with the other network's tail: one RCCL group launch for the two instead of two launches that
+        # would both sit exposed behind the backward pass.
+        self.deferred = set()
+        if hook_streams:
+            for last in seg_last:
+                b = self.bucket_of[last]
+                s0, e0 = self.buckets[b]
+                if (e0 - s0) <= 2 * tail and len(self.buckets) > len(seg_last):
+                    self.deferred.add(b)
         self._ready = [0] * len(self.buckets)
         self._reduced = [False] * len(self.buckets)
         self._work = []
@@ -200,7 +227,7 @@ class GradSync:
             # Functions hand None to autograd (gradsink.py)
             for i, p in enumerate(flat.tensors):
                 st = hook_streams.get(id(p)) if hook_streams else None
-                if st is not None:
+                if isinstance(st, torch.cuda.Stream):            # (any other key only groups the parameters into segments)
                     with torch.cuda.stream(st):
                         p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[i]))
                 else:
@@ -209,7 +236,7 @@ class GradSync:
     def _make_hook(self, b):
         def hook(_param):
             self._ready[b] += 1
-            if self._ready[b] == self.sizes[b] and not self._reduced[b]:
+            if self._ready[b] == self.sizes[b] and not self._reduced[b] and b not in self.deferred:
                 s, e = self.buckets[b]
                 self._reduced[b] = True
                 # the bucket's gradients were written on the compute and side streams of ITS network only: wait for
@@ -228,8 +255,11 @@ class GradSync:
         """Wait for the step's all-reduces (any bucket whose hooks did not all fire is reduced now)."""
         gradsink.fence()                     # gradients accumulated on the side / per-network streams
         if self.world > 1:
-            for b, (s, e) in enumerate(self.buckets):
-                if not self._reduced[b]:
+            rest = [(s, e) for b, (s, e) in enumerate(self.buckets) if not self._reduced[b]]
+            if self.comm is not None and len(rest) > 1 and hasattr(self.comm, "all_reduce_ranges_"):
+                self.comm.all_reduce_ranges_(self.flat.grads, rest)        # the deferred tails (and anything whose hooks did not fire)
+            else:
+                for s, e in rest:
                     self._reduce(s, e)
             for w in self._work:
                 w.wait()

@@ -51,25 +51,29 @@ def target(param):
 # Side streams for sunk weight gradients.  A weight gradient is needed by nobody until the optimiser step, so
 # when it is accumulated in place (no tensor handed back to autograd) its kernel can run on a side stream next
 # to the data-gradient chain that the rest of backward is waiting for.  One side stream per compute stream.
-# `join()` makes the current stream wait for all of them: call it before reading the gradients (dp.FusedAdam.step
-# and dp.GradSync.finish do) and before the scratch pool is recycled (MonodepthTrainer.process_batch does).
+#
+# The streams, and the events of gradients that the loss chain hands to autograd before they are complete, belong to a
+# StreamSet.  A trainer owns one (MonodepthTrainer.streams) and makes it the ACTIVE set of its thread while it builds the
+# graph; every autograd Function of this package captures the active set in its forward and uses THAT set in its backward
+# (which the engine runs on another thread), so two trainers in one process -- a training and an evaluation model, two
+# models in a notebook -- never see each other's streams or pending events.  Code that runs the operators without a
+# trainer gets the process-wide default set.  `join()` / `fence()` at module level cover every live set: call them before
+# reading gradients (dp.FusedAdam.step and dp.GradSync.finish do).  The first use of a side stream inside a backward pass
+# also queues a fence for the END of that pass (autograd's queue_callback: it runs on the thread and stream that called
+# backward()), so whatever reads `.grad` next -- a stock torch optimiser, clip_grad_norm_ -- is ordered behind the side
+# streams whichever loss produced the gradients (the fused loss chain, a supervised loss on the network's outputs, ...).
 # ---------------------------------------------------------------------------------------------
+import contextlib
 import os
+import threading
+import weakref
 
 import torch
 
-_side = {}          # (device index, compute stream handle) -> (compute stream, its side stream)
 _enabled = os.environ.get("DVS_WGRAD_STREAM", "1") != "0"
 # DVS_WGRAD_STREAM=shared: both networks' weight gradients on ONE side stream (three streams per process instead of four)
 _shared = os.environ.get("DVS_WGRAD_STREAM", "1") == "shared"
-
-
-def enable_side_streams(on):
-    """Turn the weight-gradient side streams on / off (off: every kernel runs on its compute stream, which is what
-    per-kernel timing wants)."""
-    global _enabled
-    join()
-    _enabled = bool(on)
+_PRIORITY_DEFAULT = {"side": "normal", "pose": "normal"}
 
 
 def _priority(kind):
@@ -84,68 +88,159 @@ def _priority(kind):
     return {"low": least, "high": greatest}.get(want, 0)
 
 
-_PRIORITY_DEFAULT = {"side": "normal", "pose": "normal"}
+_sets = weakref.WeakSet()           # every live StreamSet (module-level join / fence / reset cover all of them)
+_tls = threading.local()
+
+
+class StreamSet:
+    """Side streams (one per compute stream) and pending-gradient events of one owner."""
+
+    def __init__(self):
+        self.side = {}          # (device index, compute stream handle) -> (compute stream, its side stream)
+        self.pending = {}       # data_ptr of a gradient tensor -> event recorded on the stream that produces it
+        self._end_gid = -1      # graph task for whose end a fence has been queued
+        _sets.add(self)
+
+    # ---- side streams
+    def side_stream(self):
+        """Side stream paired with the current stream, or None when disabled.  Called from backward code: the first call of
+        a backward pass queues the end-of-pass fence."""
+        if not _enabled:
+            return None
+        cur = torch.cuda.current_stream()
+        key = (cur.device_index, cur.cuda_stream)
+        pair = self.side.get(key)
+        if pair is None:
+            shared = None
+            if _shared:                          # one side stream per device, whatever the compute stream
+                for (dev, _), (_, side) in self.side.items():
+                    if dev == cur.device_index:
+                        shared = side
+            pair = self.side[key] = (cur, shared if shared is not None
+                                     else torch.cuda.Stream(device=cur.device, priority=_priority("side")))
+        self.queue_end_fence()
+        return pair[1]
+
+    def queue_end_fence(self):
+        """Inside an engine-driven backward pass: fence() once, when the pass ends, on the caller's thread and stream.
+        (Keyed by the engine's graph-task id, so a pass that died with an exception does not mute the next one.)"""
+        gid = torch._C._current_graph_task_id()
+        if gid == -1 or gid == self._end_gid:     # not inside backward() (a direct call), or already queued for this pass
+            return
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self.fence)
+            self._end_gid = gid
+        except Exception:
+            pass
+
+    def join(self):
+        """The current stream waits for every side stream of its device."""
+        if self.side:
+            cur = torch.cuda.current_stream()
+            for (dev, _), (_, side) in self.side.items():
+                if dev == cur.device_index:
+                    cur.wait_stream(side)
+
+    def fence(self):
+        """The current stream waits for every stream that can hold gradient-producing work: the side streams AND their
+        compute streams (BatchNorm / head gradients are accumulated on the compute stream, DepthNet and PoseNet use
+        different ones)."""
+        if self.side:
+            cur = torch.cuda.current_stream()
+            for (dev, handle), (comp, side) in self.side.items():
+                if dev != cur.device_index:
+                    continue
+                if side.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(side)
+                if handle != cur.cuda_stream:
+                    cur.wait_stream(comp)
+
+    def reset(self):
+        self.join()
+        self.side.clear()
+
+    # ---- gradients handed to autograd before their producer stream has finished (loss-chain backward by scale)
+    def set_pending(self, tensor, event):
+        self.pending[tensor.data_ptr()] = event
+
+    def wait_pending(self, tensor):
+        """The current stream waits for the producer of `tensor`, if one was registered.  Fail safe: while gradients are
+        pending and `tensor` is not one of them (autograd summed or copied it on the way -- a second consumer, a hook),
+        wait for ALL pending producers rather than for none."""
+        if self.pending and tensor is not None:
+            ev = self.pending.pop(tensor.data_ptr(), None)
+            cur = torch.cuda.current_stream()
+            if ev is not None:
+                cur.wait_event(ev)
+            else:
+                for e in self.pending.values():
+                    cur.wait_event(e)
+                self.pending.clear()
+
+    def clear_pending(self):
+        self.pending.clear()
+
+
+_default = StreamSet()
+
+
+def active():
+    """The StreamSet a Function should capture in its forward: the one its trainer activated on this thread, else the
+    process-wide default."""
+    return getattr(_tls, "cur", None) or _default
+
+
+@contextlib.contextmanager
+def use(streams):
+    prev = getattr(_tls, "cur", None)
+    _tls.cur = streams
+    try:
+        yield streams
+    finally:
+        _tls.cur = prev
+
+
+def of(ctx):
+    """The set a Function captured in its forward (`ctx.gs = gradsink.active()`), or the default for a ctx without one."""
+    return getattr(ctx, "gs", None) or _default
+
+
+def enable_side_streams(on):
+    """Turn the weight-gradient side streams on / off (off: every kernel runs on its compute stream, which is what
+    per-kernel timing wants)."""
+    global _enabled
+    join()
+    _enabled = bool(on)
 
 
 def side_stream():
-    """Side stream paired with the current stream, or None when disabled."""
-    if not _enabled:
-        return None
-    cur = torch.cuda.current_stream()
-    key = (cur.device_index, cur.cuda_stream)
-    pair = _side.get(key)
-    if pair is None:
-        shared = None
-        if _shared:                          # one side stream per device, whatever the compute stream
-            for (dev, _), (_, side) in _side.items():
-                if dev == cur.device_index:
-                    shared = side
-        pair = _side[key] = (cur, shared if shared is not None else torch.cuda.Stream(device=cur.device, priority=_priority("side")))
-    return pair[1]
-
-
-_pending = {}       # data_ptr of a gradient tensor -> event recorded on the stream that produces it
+    return active().side_stream()
 
 
 def set_pending(tensor, event):
-    """`tensor` (a gradient handed to autograd) is being written on another stream; its consumer calls wait_pending."""
-    _pending[tensor.data_ptr()] = event
+    active().set_pending(tensor, event)
 
 
 def wait_pending(tensor):
-    """The current stream waits for the producer of `tensor`, if one was registered (loss-chain backward by scale).
-    Fail safe: while gradients are pending and `tensor` is not one of them (autograd summed or copied it on the way --
-    a second consumer, a hook), wait for ALL pending producers rather than for none."""
-    if _pending and tensor is not None:
-        ev = _pending.pop(tensor.data_ptr(), None)
-        cur = torch.cuda.current_stream()
-        if ev is not None:
-            cur.wait_event(ev)
-        else:
-            for e in _pending.values():
-                cur.wait_event(e)
-            _pending.clear()
+    active().wait_pending(tensor)
 
 
 def clear_pending():
-    _pending.clear()
+    active().clear_pending()
 
 
 def reset_streams():
-    """Drop the side streams (after join()).  A process that builds a second trainer would otherwise keep the first one's
-    compute / side streams alive here, and HIP multiplexes all live streams onto a handful of hardware queues: the new
+    """Drop the side streams of every set (after join()).  A process that builds a second trainer would otherwise keep the
+    first one's compute / side streams alive, and HIP multiplexes all live streams onto a handful of hardware queues: the new
     trainer's four streams then share queues and lose part of their overlap (bench.py: batch-4 step 14.1 vs 12.9 ms)."""
-    join()
-    _side.clear()
+    for s in list(_sets):
+        s.reset()
 
 
 def join():
-    """The current stream waits for every side stream of its device."""
-    if _side:
-        cur = torch.cuda.current_stream()
-        for (dev, _), (_, side) in _side.items():
-            if dev == cur.device_index:
-                cur.wait_stream(side)
+    """The current stream waits for every side stream of its device, whichever set owns it."""
+    for s in list(_sets):
+        s.join()
 
 
 def fence_for(params):
@@ -153,7 +248,7 @@ def fence_for(params):
     i.e. its gradient came through autograd on the current stream or from code that does not note)."""
     notes = [getattr(getattr(p, "_dvs_sink", None), "streams", ()) or () for p in params]
     if not any(notes):
-        if _side:
+        if any(s.side for s in _sets):
             fence()                # GPU run, nothing noted: be safe
         return                     # CPU tensors
     if not all(notes):
@@ -170,15 +265,7 @@ def fence_for(params):
 
 
 def fence():
-    """The current stream waits for every stream that can hold gradient-producing work: the side streams AND their
-    compute streams (BatchNorm / head gradients are accumulated on the compute stream, DepthNet and PoseNet use
-    different ones).  Used before a gradient bucket is handed to the all-reduce."""
-    if _side:
-        cur = torch.cuda.current_stream()
-        for (dev, handle), (comp, side) in _side.items():
-            if dev != cur.device_index:
-                continue
-            if side.cuda_stream != cur.cuda_stream:
-                cur.wait_stream(side)
-            if handle != cur.cuda_stream:
-                cur.wait_stream(comp)
+    """The current stream waits for every stream of every set that can hold gradient-producing work.  Used before a
+    gradient bucket is handed to the all-reduce."""
+    for s in list(_sets):
+        s.fence()

@@ -107,7 +107,10 @@ class MonodepthTrainer:
         use_stream = tr.get("pose_stream", os.environ.get("DVS_POSE_STREAM", "1") != "0")
         self.pose_stream = (torch.cuda.Stream(device=self.device, priority=gradsink._priority("pose"))
                             if use_stream and torch.device(self.device).type == "cuda" else None)
-        ops.chain_aux_stream = self.pose_stream          # loss-chain backward by scale (DVS_CHAIN_SPLIT=1) runs its coarse scales there
+        # side streams of the weight gradients and the events of the loss chain's late gradients: owned by this trainer, active
+        # while it builds a step's graph (gradsink.StreamSet); the loss chain's backward by scale runs its coarse scales on
+        # the PoseNet stream (passed per call: ops.loss_chain(aux_stream=))
+        self.streams = gradsink.StreamSet()
         self._noise = None   # test hook: inject the reference's torch.randn tie-break noise [S,B,2,H,W]
         # The unchanged caller (vo/train.py:114-117,173-199) builds a stock torch.optim.Adam over plain parameters and
         # calls zero_grad(set_to_none=True) every step.  Unless told otherwise the trainer moves the two networks'
@@ -141,11 +144,14 @@ class MonodepthTrainer:
         for key in sample:
             if isinstance(sample[key], torch.Tensor):
                 sample[key] = sample[key].to(self.device, non_blocking=True)
-        gradsink.join()                                          # side-stream kernels of the previous step
+        gradsink.join()                                          # side-stream kernels of the previous step (every set's)
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
         if self.arena is not None and torch.is_grad_enabled():
             self._arena_prepare()
-        ops.chain_aux_stream = self.pose_stream                  # follows the attribute (bench.py switches it off to time kernels)
+        with gradsink.use(self.streams):                          # the Functions of this step capture the trainer's stream set
+            return self._process_batch(sample)
+
+    def _process_batch(self, sample):
         if self.pose_stream is None:
             outputs = LazyOutputs(self.depth_net(sample[("target_image", 0)]))
             outputs.update(self._predict_poses(sample))
@@ -221,7 +227,8 @@ class MonodepthTrainer:
 
     def _chain_kwargs(self, seed):
         return dict(noise=self._noise, seed=seed, auto_mask=self.auto_mask, min_depth=self.min_depth,
-                    max_depth=self.max_depth, ssim_ratio=self.ssim_ratio, smoothness_ratio=self.smoothness_ratio)
+                    max_depth=self.max_depth, ssim_ratio=self.ssim_ratio, smoothness_ratio=self.smoothness_ratio,
+                    aux_stream=self.pose_stream)          # follows the attribute (bench.py switches it off to time kernels)
 
     def _fused_losses(self, sample, outputs):
         """_generate_images_pred + _compute_losses (learner_new.py:132-258) as one fused launch."""

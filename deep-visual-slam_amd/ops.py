@@ -21,6 +21,8 @@ def _f32c(t):
 class _PoseToMat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, axisangle, translation, invert):
+        from . import gradsink
+        ctx.gs = gradsink.active()
         aa = _f32c(axisangle.reshape(-1, 3))
         tr = _f32c(translation.reshape(-1, 3))
         B = aa.shape[0]
@@ -35,7 +37,7 @@ class _PoseToMat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dM):
         from . import gradsink
-        gradsink.wait_pending(dM)
+        gradsink.of(ctx).wait_pending(dM)
         aa, tr = ctx.saved_tensors
         dM = _f32c(dM)
         d_aa, d_tr = torch.empty_like(aa), torch.empty_like(tr)
@@ -68,11 +70,10 @@ def chain_workspace_bytes(cfg):
     return [s.value for s in sizes]
 
 
-# Loss-chain backward by scale on two streams (see _LossChain.backward): used when the trainer has given its second stream
-# (MonodepthTrainer sets chain_aux_stream to the PoseNet stream) AND every gradient it hands out late goes to a consumer that
-# waits for it (gradsink.wait_pending: the disparity heads' and the pose-matrix backward); DVS_CHAIN_SPLIT=0 switches it off.
+# Loss-chain backward by scale on two streams (see _LossChain.backward): used when the caller has given a second stream
+# (loss_chain(aux_stream=...): MonodepthTrainer passes its PoseNet stream) AND every gradient it hands out late goes to a consumer
+# that waits for it (StreamSet.wait_pending: the disparity heads' and the pose-matrix backward); DVS_CHAIN_SPLIT=0 switches it off.
 _CHAIN_SPLIT = os.environ.get("DVS_CHAIN_SPLIT", "1") != "0"
-chain_aux_stream = None
 
 
 class _LossChain(torch.autograd.Function):
@@ -122,23 +123,19 @@ class _LossChain(torch.autograd.Function):
                     extra += [g, c]
         check(_lib.lib().dvs_chain_fwd(C.byref(cfg), C.byref(io), _lib.stream()), "dvs_chain_fwd")
         ctx.save_for_backward(target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps)
-        ctx.opts = dict(opts)
+        ctx.opts = {k: v for k, v in opts.items() if k != "aux_stream"}
         ctx.nbwd = nb[3]
         ctx.split_ok = bool(opts.get("split_ok", False))
+        ctx.aux_stream = opts.get("aux_stream")          # the caller's second stream (MonodepthTrainer: the PoseNet stream)
+        from . import gradsink
+        ctx.gs = gradsink.active()
         ctx.mark_non_differentiable(sel, *extra)
         return (losses, sel, *extra)
 
     @staticmethod
     def backward(ctx, d_losses, *_unused):
-        # The chain is the first node of the step's backward pass: queue a join of the weight-gradient side streams for
-        # the END of this backward pass (the engine runs the callback in the thread that called backward(), on its
-        # current stream), so that whatever reads the sunk gradients next -- any optimiser, clip_grad_norm_ -- is ordered
-        # behind the kernels that produce them.
-        from . import gradsink as _gs
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_gs.join)
-        except Exception:
-            pass                                  # not inside an engine-driven backward (e.g. torch.autograd.functional)
+        # (The end-of-backward fence of the weight-gradient side streams is queued by the first Function that uses a side
+        # stream -- gradsink.StreamSet.side_stream -- whichever loss the pass started from.)
         target, src_l, src_r, K, inv_K, T_l, T_r, noise, sel, stats, *disps = ctx.saved_tensors
         B, _, H, W = target.shape
         dev = target.device
@@ -164,17 +161,17 @@ class _LossChain(torch.autograd.Function):
         g.d_T[0], g.d_T[1] = ptr(d_T[0]), ptr(d_T[1])
         bwd_partials = torch.empty(ctx.nbwd // 4, device=dev, dtype=torch.float32)
         g.bwd_partials = ptr(bwd_partials)
-        aux = chain_aux_stream if (_CHAIN_SPLIT and S > 1 and ctx.split_ok) else None
+        aux = ctx.aux_stream if (_CHAIN_SPLIT and S > 1 and ctx.split_ok) else None
         if aux is None:
             check(_lib.lib().dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), _lib.stream()), "dvs_chain_bwd")
             return (None, None, None, None, None, None, d_T[0], d_T[1], None, *d_disps)
         # By scale: the decoder's backward needs d disp_0 first and the coarser scales only later, the PoseNet stream is
         # idle until d_T exists.  Scale 0 on this stream; scales 1 .. S-1 one after the other on `aux`, then the d_T
         # reduction there; the consumers (disparity heads, pose-matrix backward) wait for their own event.
-        from . import gradsink
+        gs = ctx.gs
         l = _lib.lib()
         main = torch.cuda.current_stream()
-        gradsink.clear_pending()
+        gs.clear_pending()
         aux.wait_stream(main)                                # d_losses, saved state, the fresh gradient buffers
         g.scale_begin, g.scale_end, g.phase = 0, 1, 1
         check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), main.cuda_stream), "dvs_chain_bwd")
@@ -186,14 +183,14 @@ class _LossChain(torch.autograd.Function):
                 check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), aux.cuda_stream), "dvs_chain_bwd")
                 ev = torch.cuda.Event()
                 ev.record(aux)
-                gradsink.set_pending(d_disps[s], ev)
+                gs.set_pending(d_disps[s], ev)
             aux.wait_event(ev_a)                             # scale 0's partial sums
             g.scale_begin, g.scale_end, g.phase = 0, 0, 2
             check(l.dvs_chain_bwd(C.byref(cfg), C.byref(io), C.byref(g), aux.cuda_stream), "dvs_chain_bwd")
             ev_t = torch.cuda.Event()
             ev_t.record(aux)
         for t in d_T:
-            gradsink.set_pending(t, ev_t)
+            gs.set_pending(t, ev_t)
         # everything the aux-stream kernels read or write must outlive them in the caching allocator's eyes -- including
         # the contiguous copies _f32c may have made of the images / intrinsics / poses in the forward
         for t in d_disps[1:] + d_T + [bwd_partials, d_losses, sel, stats, target, src_l, src_r, K, inv_K, T_l, T_r] + list(disps):
@@ -202,11 +199,11 @@ class _LossChain(torch.autograd.Function):
 
 
 def loss_chain(target, src_l, src_r, K, inv_K, T_l, T_r, disps, noise=None, seed=0, materialize=False,
-               auto_mask=True, min_depth=0.1, max_depth=10.0, ssim_ratio=0.85, smoothness_ratio=1e-3):
+               auto_mask=True, min_depth=0.1, max_depth=10.0, ssim_ratio=0.85, smoothness_ratio=1e-3, aux_stream=None):
     """Fused view-synthesis loss chain.  Returns (losses[S], sel[B,H,W] uint8, extras) where extras is a
     per-scale list of dicts {disp_up, depth, grid:(l,r), color:(l,r)} when materialize=True, else []."""
     opts = dict(auto_mask=auto_mask, min_depth=min_depth, max_depth=max_depth, ssim_ratio=ssim_ratio,
-                smoothness_ratio=smoothness_ratio, seed=seed, materialize=materialize)
+                smoothness_ratio=smoothness_ratio, seed=seed, materialize=materialize, aux_stream=aux_stream)
     # the backward may hand d disp_1.. and d T out before they are complete (computed on a second stream) only if their
     # consumers are the nodes that wait for them: the disparity heads and the pose-matrix Function
     def fn_name(t):

@@ -54,6 +54,13 @@ const char* dvs_arch(void);
 int dvs_set_deterministic(int on);
 int dvs_get_deterministic(void);
 
+/* Peak probes (ABI 7; measurement aids of bench.py's `measured_peaks`, timed by the caller with events on `stream`):
+ *   dvs_peak_probe_mfma: one wave per SIMD on every CU runs 4 * iters independent v_mfma_f32_32x32x2_f32 from registers; *flops
+ *                        (host) = the flops the launch executes.  scratch: any device buffer of >= 4 bytes (never written).
+ *   dvs_peak_probe_copy: a 16-byte-per-lane streaming copy of `bytes` (multiple of 16) from src to dst: 2 * bytes of HBM traffic. */
+int dvs_peak_probe_mfma(float* scratch, int iters, double* flops, void* stream);
+int dvs_peak_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around each main kernel (used by
  * bench.py for the roofline line; off by default).  dvs_profile_enable(1) clears the counters;
  * dvs_profile_read synchronises the recorded events of one slot and returns the accumulated
@@ -157,7 +164,10 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
  *   dvs_conv3x3_wino_wgrad: dw [Cout][3][3][Cin] += the weight gradient of that convolution from x [B,H,W,Cin] and dy [B,H,W,Cout]
  *                         (dL/dg = G^T [sum over tiles (A dY A^T) o (B^T d B)] G), the tile range split over about
  *                         target_workgroups (0 = default) workgroups that add into dw with float atomics (plain adds when
- *                         one workgroup owns a block).  Cin % 32 == 0, Cout % 32 == 0, tensors < 2 GiB. */
+ *                         one workgroup owns a block).  Cin % 32 == 0, Cout % 32 == 0, tensors < 1 GiB (ABI 7: its offsets carry two mask bits).
+ *                         dw may be shared with other launches only through float atomics: with one tile range per block (small
+ *                         problems) the kernel adds with plain read-modify-writes, so no OTHER launch may touch the same dw block
+ *                         concurrently (one stream per weight tensor, as the Python side keeps it). */
 int dvs_wino_weights(const float* w, float* u, int Cout, int Cin, int flip, void* stream);
 int dvs_conv3x3_wino_gen(const float* x, const float* x2, const float* u, const float* bias, float* y, int B, int H, int W, int C1, int C2,
                          int Cout, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream);
@@ -169,10 +179,20 @@ int dvs_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, int B, in
  *   `upsample`).  dact = 0: dy is the gradient in front of the activation (dvs_act_bwd took the derivative and the bias gradient);
  *   dact = 1 (ReLU) / 2 (ELU): dy is multiplied by act'(y_out) as it is loaded (y_out [B,H,W,Cout] = the forward output) and
  *   dbias [Cout] (NULL: none) += its column sums.  One launch per source, each adding into its channel range of dw.
- *   C1, C2, Cout % 32 == 0, H, W >= 2 (even with `upsample`), tensors < 2 GiB.  Replaces the weight / bias gradient of
+ *   C1, C2, Cout % 32 == 0, H, W >= 2 (even with `upsample`), tensors < 1 GiB; the same exclusivity rule for dw as above.  Replaces the weight / bias gradient of
  *   model/layers.py:26-41 Conv3x3 (+ ELU of ConvBlock, :106-118) inside model/depth_decoder.py:52-62. */
 int dvs_conv3x3_wino_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
                                int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, void* stream);
+/*   Ordered weight gradient (ABI 7): the `_ws` forms take a partial-sum workspace (device, `workspace_bytes` >= what
+ *   dvs_conv3x3_wino_wgrad_workspace returns for the same sizes; for the `_gen` form: the larger of its two sources, Cin = max(C1, C2))
+ *   -- every workgroup stores its 32 x 32 x 9 block there and a second kernel adds the blocks into dw in split order: no float
+ *   atomics on dw, bit-identical results run to run (the deterministic backward).  workspace = NULL: the atomic form above. */
+size_t dvs_conv3x3_wino_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int target_workgroups);
+int dvs_conv3x3_wino_wgrad_ws(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups,
+                              float* workspace, size_t workspace_bytes, void* stream);
+int dvs_conv3x3_wino_wgrad_gen_ws(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H,
+                                  int W, int C1, int C2, int Cout, int upsample, int dact, int target_workgroups, float* workspace,
+                                  size_t workspace_bytes, void* stream);
 int dvs_wino_weights_batch(const void* table, int n_entries, int total_workgroups, void* stream);
 int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats, int stat_groups,
                          int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad, void* stream);

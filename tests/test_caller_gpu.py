@@ -298,3 +298,142 @@ def test_one_line_optimizer_swap_keeps_the_caller_sequence(gpu_device):
         n_bad += int((d > 0.2 * LR).sum())
         n_all += d.numel()
     assert n_bad / n_all < 0.02, n_bad / n_all
+
+
+def _train_mono_step(learner, optimizer, sample, use_amp, scaler=None, poison=None):
+    """vo/train.py:173-199 line for line (`use_amp` defaults to True there: vo/train.py:44); `poison` plants a non-finite
+    gradient between backward and the scaler's step (test hook)."""
+    from torch.amp import autocast
+    optimizer.zero_grad(set_to_none=True)
+    if use_amp:
+        with autocast(device_type="cuda", enabled=use_amp):
+            outputs, losses = learner.process_batch(sample)
+        total_loss = losses["loss"]
+        scaler.scale(total_loss).backward()
+        if poison is not None:
+            poison()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        outputs, losses = learner.process_batch(sample)
+        total_loss = losses["loss"]
+        total_loss.backward()
+        optimizer.step()
+    total_loss = total_loss.detach()
+    for key in losses:
+        losses[key] = losses[key].detach().cpu()
+    return total_loss, outputs, losses
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_amp_branch_of_train_mono_step(gpu_device, fused):
+    """The branch the reference takes by default (vo/train.py:44 `use_amp` = True, :126-128 GradScaler, :177-185 autocast around
+    process_batch, scaler.scale(loss).backward(), scaler.step, scaler.update), with stock Adam and with dp.FusedAdam.  Every kernel
+    of this package computes in fp32 whatever autocast says and GradScaler's factor is a power of two, so two AMP steps must
+    land on the weights of two plain steps (same criterion as the optimiser-swap test: Adam's first steps are sign-like); an
+    injected inf must skip the optimiser step and halve the scale."""
+    from torch.amp import GradScaler
+    from deep_visual_slam_amd import dp, gradsink, synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    sample = synth.parity_sample(B, H, W)
+    g = torch.Generator().manual_seed(7)
+    noises = [torch.stack([torch.randn(B, 2, H, W, generator=g) for _ in range(4)]).to(gpu_device) for _ in range(3)]
+    results = []
+    for use_amp in (False, True):
+        gradsink.reset_streams()
+        dn, pn, _, _ = _nets(gpu_device, seed=0)
+        dn.train()
+        pn.train()
+        if fused:
+            flat = dp.FlatParams(dp.trainable_parameters(dn, pn))
+            optimizer = dp.FusedAdam(flat, lr=LR, params=list(dn.parameters()) + list(pn.parameters()))
+        else:
+            optimizer = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), lr=LR)
+        scaler = GradScaler() if use_amp else None
+        learner = MonodepthTrainer(dn, pn, _cfg(), gpu_device)
+        seen = []
+        for it in range(2):
+            learner._noise = noises[it]
+            _, outputs, losses = _train_mono_step(learner, optimizer, dict(sample), use_amp, scaler)
+            seen.append({k: float(v) for k, v in losses.items()})
+            assert outputs[("disp", 0)].dtype == torch.float32
+        torch.cuda.synchronize()
+        weights = {k: v.detach().cpu().clone() for k, v in list(dn.named_parameters()) + list(pn.named_parameters())}
+        results.append((seen, weights))
+        if use_amp:
+            # third step with a poisoned gradient: no weight may move, the scale halves (GradScaler's backoff)
+            scale0 = scaler.get_scale()
+            p_bad = dict(dn.named_parameters())["decoder.9.conv.conv.weight"]
+
+            def poison():
+                p_bad.grad.view(-1)[0] = float("inf")
+
+            learner._noise = noises[2]
+            _train_mono_step(learner, optimizer, dict(sample), True, scaler, poison)
+            torch.cuda.synchronize()
+            for k, v in list(dn.named_parameters()) + list(pn.named_parameters()):
+                assert torch.equal(v.detach().cpu(), weights[k]), k
+            assert scaler.get_scale() == 0.5 * scale0
+            # and the step after that trains again
+            _train_mono_step(learner, optimizer, dict(sample), True, scaler)
+            torch.cuda.synchronize()
+            moved = max(float((v.detach().cpu() - weights[k]).abs().max()) for k, v in dn.named_parameters() if ".fc." not in k)
+            assert 0.0 < moved <= 2.0 * LR
+    (l_a, w_a), (l_b, w_b) = results
+    for k in l_a[0]:
+        assert abs(l_a[0][k] - l_b[0][k]) < 1e-5 * abs(l_a[0][k])
+        assert abs(l_a[1][k] - l_b[1][k]) < 1e-3 * abs(l_a[1][k])
+    n_bad = n_all = 0
+    for k in w_a:
+        d = (w_a[k] - w_b[k]).abs()
+        n_bad += int((d > 0.2 * LR).sum())
+        n_all += d.numel()
+    assert n_bad / n_all < 0.02, n_bad / n_all
+
+
+def test_loss_that_bypasses_the_chain_joins_the_side_streams(gpu_device):
+    """the trainer moves the networks into its arena (gradient sinks, weight gradients on side streams), but the
+    backward pass need not start at the fused loss chain -- a supervised loss on DepthNet's outputs, clip_grad_norm_, a stock
+    optimiser.  The first side-stream use of a pass queues the end-of-pass fence (gradsink.StreamSet), so the stock optimiser
+    reads complete gradients: two steps against the same sequence without the arena (DVS_ARENA=0 path: plain autograd)."""
+    from deep_visual_slam_amd import gradsink, synth
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    sample = synth.parity_sample(B, H, W)
+    x = sample[("target_image", 0)].to(gpu_device)
+    torch.manual_seed(11)
+    gt = [torch.rand(B, 1, H >> s, W >> s, device=gpu_device) for s in range(4)]
+    results = []
+    for arena in (False, True):
+        gradsink.reset_streams()
+        dn, pn, _, _ = _nets(gpu_device, seed=4)
+        dn.train()
+        cfg = _cfg()
+        cfg["Train"]["arena"] = arena
+        learner = MonodepthTrainer(dn, pn, cfg, gpu_device)
+        assert (learner.arena is not None) == arena
+        optimizer = torch.optim.Adam(dn.parameters(), lr=LR)
+        grads = None
+        for it in range(2):
+            optimizer.zero_grad(set_to_none=True)
+            if arena:
+                learner._arena_prepare()                      # what process_batch does at the start of a step
+            with gradsink.use(learner.streams):
+                out = dn(x)
+            loss = sum(((out[("disp", s)] - gt[s]) ** 2).mean() for s in range(4))
+            loss.backward()
+            total = torch.nn.utils.clip_grad_norm_(dn.parameters(), 1e9)      # reads every .grad right after backward
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in dn.named_parameters() if p.grad is not None}
+            optimizer.step()
+        torch.cuda.synchronize()
+        results.append((float(loss), float(total), grads, {k: v.detach().cpu().clone() for k, v in dn.named_parameters()}))
+    (la, ta, ga, wa), (lb, tb, gb, wb) = results
+    assert abs(la - lb) < 1e-4 * abs(la) and abs(ta - tb) < 2e-3 * abs(ta)
+    for k in ga:                                               # first-step gradients: same weights, same kernels
+        assert rel(gb[k], ga[k]) < 5e-3, k
+    n_bad = n_all = 0
+    for k in wa:
+        d = (wa[k] - wb[k]).abs()
+        n_bad += int((d > 0.2 * LR).sum())
+        n_all += d.numel()
+    assert n_bad / n_all < 0.02, n_bad / n_all

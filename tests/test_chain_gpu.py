@@ -177,28 +177,29 @@ def test_backward_by_scale_on_two_streams_equals_one_launch(gpu_device):
     noise = torch.randn(4, B, 2, H, W, device=gpu_device)
 
     def run(split):
-        old = (ops._CHAIN_SPLIT, ops.chain_aux_stream)
-        ops._CHAIN_SPLIT, ops.chain_aux_stream = split, (torch.cuda.Stream(device=gpu_device) if split else None)
+        old = ops._CHAIN_SPLIT
+        ops._CHAIN_SPLIT = split
+        aux = torch.cuda.Stream(device=gpu_device) if split else None
         try:
             f = [t.clone().requires_grad_(True) for t in feats]
             a, t = aa.clone().requires_grad_(True), tt.clone().requires_grad_(True)
             disps = [DC.head_conv2d(f[s], ws[s], bs[s], 0, 1, "sigmoid") for s in range(4)]
             T_l, T_r = ops.pose_to_mat(a[0], t[0], True), ops.pose_to_mat(a[1], t[1], False)
-            losses, _, _ = ops.loss_chain(tgt, left, right, K, inv_K, T_l, T_r, disps, noise=noise)
+            losses, _, _ = ops.loss_chain(tgt, left, right, K, inv_K, T_l, T_r, disps, noise=noise, aux_stream=aux)
             assert ops._LossChain is not None
             (losses * torch.tensor([1.0, 0.5, 0.25, 0.125], device=gpu_device)).sum().backward()
             torch.cuda.synchronize()
             return [x.grad.clone() for x in f] + [a.grad.clone(), t.grad.clone()]
         finally:
-            ops._CHAIN_SPLIT, ops.chain_aux_stream = old
+            ops._CHAIN_SPLIT = old
 
     from deep_visual_slam_amd import gradsink
-    seen, orig = [], gradsink.set_pending
-    gradsink.set_pending = lambda t, ev: (seen.append(t.data_ptr()), orig(t, ev))[1]
+    seen, orig = [], gradsink.StreamSet.set_pending
+    gradsink.StreamSet.set_pending = lambda self, t, ev: (seen.append(t.data_ptr()), orig(self, t, ev))[1]
     try:
         one, two = run(False), run(True)
     finally:
-        gradsink.set_pending = orig
+        gradsink.StreamSet.set_pending = orig
     assert len(seen) == 5                                 # d disp_1..3 and the two d T were handed out with events
     for g1, g2 in zip(one, two):
         assert torch.isfinite(g2).all()

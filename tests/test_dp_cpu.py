@@ -155,3 +155,76 @@ def test_bucket_layout_follows_the_streams():
         assert e - s <= max((1 << 20) // 4 // 8, flat.tensors[i].numel()) + 256
     full = [e - s for k, (s, e) in enumerate(gs.buckets) if k not in seg_last_bucket and k + 1 not in seg_last_bucket]
     assert all(n >= (1 << 20) // 4 for n in full)
+
+
+class _RecordingComm:
+    """Stands in for dp.RcclComm on the CPU: same two entry points, carried by gloo, recording what GradSync hands it."""
+
+    def __init__(self):
+        self.calls = []
+
+    def all_reduce_(self, tensor):
+        import torch.distributed as dist
+        self.calls.append(("one", [(tensor.storage_offset(), tensor.storage_offset() + tensor.numel())]))
+        dist.all_reduce(tensor)
+
+    def all_reduce_ranges_(self, base, ranges):
+        import torch.distributed as dist
+        self.calls.append(("group", [(int(s), int(e)) for s, e in ranges]))
+        for s, e in ranges:
+            dist.all_reduce(base[s:e])
+
+    def wait(self):
+        pass
+
+
+def _worker_comm(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from deep_visual_slam_amd import dp
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    out = []
+    for use_comm in (False, True):
+        m = _model()
+        flat = dp.FlatParams(dp.trainable_parameters(m))
+        # two "networks": the first conv's parameters on one (fake) stream key, the rest on another, as bench.py keys PoseNet's
+        streams = {id(p): ("a" if i < 2 else "b") for i, p in enumerate(m.parameters())}
+        comm = _RecordingComm() if use_comm else None
+        sync = dp.GradSync(flat, bucket_bytes=256, hook_streams=streams, comm=comm)
+        # the tail rule is sized for megabyte buckets (2 MB tails); on this toy model mark each network's last bucket by hand
+        keys = [streams[id(p)] for p in flat.tensors]
+        sync.deferred = {sync.bucket_of[i] for i in range(len(keys)) if i + 1 == len(keys) or keys[i + 1] != keys[i]}
+        torch.manual_seed(100)
+        x = torch.randn(4, 3, 8, 8)
+        m(x[rank * 2:(rank + 1) * 2]).pow(2).mean().backward()
+        sync.finish()
+        out.append((flat.grads.clone().numpy(), list(sync.buckets), sorted(sync.deferred), comm.calls if comm else None))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_hands_the_comm_exactly_the_bucket_ranges():
+    """with a communicator (the direct RCCL path) GradSync must reduce exactly the element ranges the
+    torch.distributed path reduces -- every bucket once, the deferred tails as one group -- and end with the same gradients."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_comm, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        (g_plain, buckets, _, _), (g_comm, buckets2, deferred, calls) = got[rank]
+        assert buckets == buckets2
+        assert abs(g_plain - g_comm).max() == 0.0
+        handed = sorted(r for _, rs in calls for r in rs)
+        assert handed == sorted(buckets)                      # every bucket exactly once, nothing else
+        groups = [rs for kind, rs in calls if kind == "group"]
+        assert len(deferred) == 2                            # one tail per "network"
+        assert len(groups) == 1 and sorted(groups[0]) == sorted(buckets[b] for b in deferred)
