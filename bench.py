@@ -471,8 +471,26 @@ def main():
     comm = None
     # N > 1: the gradient buckets go through this repo's own RCCL C-ABI (include/dvslam_rccl.h, dp.RcclComm: a communicator on a
     # stream -- hardware queue -- of its own); DVS_ALLREDUCE=torch is the explicit switch back to torch.distributed's process group
+    comm_note = None
     if world > 1 and os.environ.get("DVS_ALLREDUCE", "rccl") == "rccl" and not rehearse:
-        comm = dp.RcclComm(device)
+        # self-test before anything is timed: a 1 M-float all-reduce through the communicator must give world_size everywhere;
+        # if the communicator cannot be built or answers wrongly on ANY rank, every rank falls back to torch.distributed (the
+        # line says so in config.allreduce) rather than losing the scaling run
+        ok = 1
+        try:
+            comm = dp.RcclComm(device)
+            probe = torch.ones(1 << 20, device=device)
+            comm.all_reduce_(probe)
+            comm.wait()
+            torch.cuda.synchronize()
+            ok = int(bool((probe == float(world)).all()))
+        except Exception as e:                    # noqa: BLE001 -- reported, not swallowed
+            ok, comm_note = 0, "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag) == 0:
+            comm = None
+            comm_note = "direct RCCL communicator failed its self-test on some rank (%s): torch.distributed carries the buckets" % (comm_note or "this rank was fine")
     trainer, flat, sync, opt, sample = build_gpu(batch, num_scales, device, rank, comm=comm)
 
     def barrier():
@@ -596,7 +614,8 @@ def main():
                           "outputs": "lazy (the per-scale view-synthesis tensors of `outputs` are materialised on first access, "
                                      "SURVEY.md section 8d; config Train.materialize_outputs times the eager variant)",
                           "streams": "single" if args.serialize else "depth | pose | 2x weight-gradient",
-                          "allreduce": (None if world == 1 else ("rccl-direct" if comm is not None else "torch.distributed " + dist.get_backend())),
+                          "allreduce": (None if world == 1 else ("rccl-direct (include/dvslam_rccl.h)" if comm is not None else "torch.distributed " + dist.get_backend()
+                                                                      + (" -- " + comm_note if comm_note else ""))),
                           "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
                "loss": loss_val, "loss_check": check,
                "kernels_ms_per_step": {k: round(v, 4) for k, v in per_step.items()},

@@ -189,9 +189,13 @@ class PackedWeights:
                 _wino_packed[w.data_ptr()] = [u, uf, w._version, tuple(w.shape), weakref.ref(w)]
 
     def release(self):
+        """Drop this pack's entries -- only its own: a late-collected owner (trainer / optimiser __del__) must not evict what a
+        newer owner has registered at the same, reused arena address (its entries are pinned to ITS weight objects)."""
         for w in self.weights:
-            _prepacked.pop(w.data_ptr(), None)
-            _wino_packed.pop(w.data_ptr(), None)
+            for table in (_prepacked, _wino_packed):
+                ent = table.get(w.data_ptr())
+                if ent is not None and ent[-1]() is w:
+                    table.pop(w.data_ptr(), None)
 
 
 def _packed_weight(w, weight):

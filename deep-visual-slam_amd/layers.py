@@ -44,7 +44,7 @@ class Conv3x3(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x, act=None, skip=None, upsample=False, passthrough=False):
-        """act / skip / upsample are fusion hooks of this port (one launch for upsample + concat + pad + conv
+        """act / skip / upsample are fusion hooks of this implementation (one launch for upsample + concat + pad + conv
         + activation); plain `conv(x)` is the reference call.  passthrough: (y, x') -- see nn_ops.conv2d."""
         pad = dict(reflect_pad=1) if self.use_refl else dict(padding=1)
         return nn_ops.conv2d(x, self.conv.weight, self.conv.bias, 1, act=act, x2=skip, upsample=upsample,

@@ -112,7 +112,7 @@ class ResnetEncoder(nn.Module):
             warnings.warn("pretrained=True: ImageNet weights are not available offline; keeping the default "
                           "initialisation (set DVS_IMAGENET_RESNET%d to a torchvision state_dict)" % num_layers)
             return
-        loaded = torch.load(path, map_location="cpu")
+        loaded = torch.load(path, map_location="cpu", weights_only=True)
         if num_input_images > 1:   # model/resnet_encoder.py:65-67
             loaded["conv1.weight"] = torch.cat([loaded["conv1.weight"]] * num_input_images, 1) / num_input_images
         self.encoder.load_state_dict(loaded)

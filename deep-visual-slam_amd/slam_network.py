@@ -22,7 +22,7 @@ from .posenet_single import PoseNet
 def _load(net, path):
     if path is None:
         return
-    sd = torch.load(path, map_location="cpu")
+    sd = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(sd, dict) and "state_dict" in sd:
         sd = sd["state_dict"]
     sd = {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in sd.items()}    # vo/train.py:28-36

@@ -252,3 +252,32 @@ def test_winograd_cost_model_and_eligibility():
     assert not DC.wino_dec_wgrad_eligible((16, 64, 3, 3), x, None)                 # Cout in 32-blocks
     assert not DC.wino_dec_wgrad_eligible((64, 80, 3, 3), x, torch.empty(2, 16, 12, 16))      # skip channels in 32-blocks
     assert not DC.wino_dec_wgrad_eligible((64, 64, 3, 3), torch.empty(2, 64, 1, 8), None)     # ReflectionPad2d(1) needs two rows
+
+
+def test_packed_weights_release_only_their_own_entries():
+    """PackedWeights.release() of a late-collected owner must leave the entries a newer owner registered at the
+    same (reused) address alone."""
+    import weakref
+    from deep_visual_slam_amd import conv as DC
+
+    class _W:                                  # stands in for a CUDA weight: release() only looks at data_ptr()
+        def __init__(self, addr):
+            self.addr = addr
+
+        def data_ptr(self):
+            return self.addr
+
+    old_w, new_w = _W(4096), _W(4096)          # the allocator handed the freed arena's address to the next arena
+    pack = DC.PackedWeights.__new__(DC.PackedWeights)
+    pack.weights = [old_w]
+    DC._prepacked[4096] = ("pack-of-new", 0, (1,), weakref.ref(new_w))
+    DC._wino_packed[4096] = ["u", "uf", 0, (1,), weakref.ref(new_w)]
+    try:
+        pack.release()
+        assert DC._prepacked[4096][0] == "pack-of-new" and DC._wino_packed[4096][0] == "u"
+        DC._prepacked[4096] = ("pack-of-old", 0, (1,), weakref.ref(old_w))
+        pack.release()
+        assert 4096 not in DC._prepacked and 4096 in DC._wino_packed
+    finally:
+        DC._prepacked.pop(4096, None)
+        DC._wino_packed.pop(4096, None)
