@@ -548,7 +548,6 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     // 128 KB: in the loop the four waves' DMA rings (RING slots of NL x 64 floats each), afterwards the accumulators of two waves
     // during the reduction.  ONE shared array: a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read.
     __shared__ float sMem[2 * 256 * 64];
-    float (*const sR)[256][64] = reinterpret_cast<float (*)[256][64]>(sMem);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
@@ -864,39 +863,34 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             if (h == 0) atomicAdd(p.dbias + co0 + r, b2);
         }
     }
-    // ---- add the four waves' accumulators: waves 2, 3 -> LDS, waves 0, 1 add; wave 1 -> LDS, wave 0 adds
-    if (wave >= 2) {
+    // ---- add the four waves' accumulators, in two passes over the register index (i < 8, then i >= 8): every wave stores its 128
+    // values of the pass (all 16 components) in LDS, and after a barrier wave w collects registers 2w, 2w + 1 of that half from all
+    // four waves -- in a fixed order: a workgroup's sum does not depend on timing --, applies G^T . G in-lane (the 16 components of a
+    // (co, ci) pair share a lane) and adds its 2 x 9 values per lane into dw.  Identical code in every wave (which registers a wave
+    // collects is an LDS address, not a register index), and all four SIMDs work through the whole epilogue: round 2's tree
+    // (waves 2, 3 -> waves 0, 1 -> wave 0, which then transformed and stored all 16 registers alone) left three of them idle for
+    // most of an epilogue that is a fifth of a batch-12 launch.
+    float (*const sP)[128][64] = reinterpret_cast<float (*)[128][64]>(sMem);     // [wave][q * 8 + (i & 7)][lane]: 32 KB each
+    const bool exclusive = p.S == 1;                       // this workgroup alone owns its block of dw
+    float* const part = p.part ? p.part + ((size_t)blk * p.S + sp) * (9 * 1024) : nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();                         // the first pass's reads are done
 #pragma unroll
         for (int q = 0; q < 16; ++q)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sR[wave - 2][q * 16 + i][lane] = acc[q][i];
-    }
-    __syncthreads();
-    if (wave < 2) {
+            for (int i8 = 0; i8 < 8; ++i8) sP[wave][q * 8 + i8][lane] = acc[q][8 * half + i8];
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[q][i] += sR[wave][q * 16 + i][lane];
-    }
-    __syncthreads();
-    if (wave == 1) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sR[0][q * 16 + i][lane] = acc[q][i];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const bool exclusive = p.S == 1;                  // this workgroup alone owns its block of dw
-        float* const part = p.part ? p.part + ((size_t)blk * p.S + sp) * (9 * 1024) : nullptr;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int e = 0; e < 2; ++e) {
+            const int i = 8 * half + 2 * wave + e;         // (wave-uniform, only used in addresses)
             const int m = (i & 3) + 8 * (i >> 2) + 4 * h;  // output channel row of the block
             float u[4][4], t3[3][4];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const float s = acc[q][i] + sR[0][q * 16 + i][lane];
-                u[q >> 2][q & 3] = ((q >> 2) == 3) != ((q & 3) == 3) ? -s : s;     // the signs left out of the loop's dY transform
+                const float* c = &sP[0][q * 8 + 2 * wave + e][lane];
+                const float sv = ((c[0] + c[128 * 64]) + c[2 * 128 * 64]) + c[3 * 128 * 64];
+                u[q >> 2][q & 3] = ((q >> 2) == 3) != ((q & 3) == 3) ? -sv : sv;   // the signs left out of the loop's dY transform
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {                  // G^T dU
