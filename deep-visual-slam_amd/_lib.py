@@ -79,6 +79,8 @@ _SIGNATURES = {
     "dvs_conv2d_dgrad": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp, C.c_int, _vp]),
     "dvs_conv2d_dgrad_res": (C.c_int, [_vp, _vp, _vp, C.POINTER(ConvDesc), _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "dvs_conv2d_wgrad": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp, C.c_int, _vp]),
+    "dvs_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc), C.POINTER(ConvFusion), C.c_int, C.c_int]),
+    "dvs_conv2d_wgrad_ws": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.POINTER(ConvFusion), _vp, C.c_int, _vp, C.c_size_t, _vp]),
     "dvs_conv2d_head_fwd": (C.c_int, [_vp, _vp, _vp, _vp, C.POINTER(ConvDesc), C.c_int, _vp]),
     "dvs_conv2d_head_bwd": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp]),
     "dvs_conv2d_head_bwd_res": (C.c_int, [_vp] * 7 + [C.POINTER(ConvDesc), C.c_int, _vp, _vp]),

@@ -64,8 +64,17 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        _check_loads(LIB)
     build_rccl(force, verbose)
     return LIB
+
+
+def _check_loads(path):
+    """dlopen the fresh library in a child process: an undefined symbol (e.g. a kernel launch stub that hipcc's host pass dropped)
+    must fail the BUILD, not the first import on the GPU box."""
+    r = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", path], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("%s does not load:\n%s" % (path, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else r.returncode))
 
 
 def build_rccl(force=False, verbose=True):

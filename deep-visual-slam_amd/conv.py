@@ -486,8 +486,12 @@ def conv2d_wgrad(x, dy, weight_shape, stride, pad, reflect, want_bias, y_out=Non
     f = _fusion(x, x2, in_scale, in_shift, in_relu, nchw_planar)
     dact = ACT[act]
     yo = _nhwc(y_out).data_ptr() if dact else None
-    check(l.dvs_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ptr(db), C.byref(d), C.byref(f), yo, dact,
-                             _lib.stream()), "dvs_conv2d_wgrad")
+    ws, nws = None, 0
+    if _WGRAD_ORDERED or _lib.deterministic():               # slab workspace: partial tiles + an ordered second pass, no atomics on dw
+        nws = l.dvs_conv2d_wgrad_workspace(C.byref(d), C.byref(f), dact, int(db is not None))
+        ws = torch.empty(nws // 4, device=dy.device, dtype=torch.float32) if nws else None
+    check(l.dvs_conv2d_wgrad_ws(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ptr(db), C.byref(d), C.byref(f), yo, dact,
+                                ptr(ws), nws, _lib.stream()), "dvs_conv2d_wgrad")
     if nchw_planar:
         dw = dw[..., :kw]
     return (None if dw_out is not None else dw), (None if db_out is not None else db)

@@ -363,6 +363,7 @@ void stem_fwd(const float* x, const float* w, float* y, float* stats, int stat_g
 
 // conv_thin.hip: weight gradient of the decoder's thin full-resolution layers (Cout 16 / 32, reflection-padded 3x3);
 // returns false (nothing launched) when the shape is not one of them
+bool thin_wgrad_shape(const ConvShape& s, const InXform& t);
 bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
                 hipStream_t st);
 bool thin_fwd(const float* x, const float* w, const float* bias, float* y, const ConvShape& s, const InXform& t, int act,

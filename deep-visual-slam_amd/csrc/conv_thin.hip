@@ -651,11 +651,20 @@ void launch_thin_dgrad(ThinDgradParams p, hipStream_t st) {
 
 }  // namespace
 
-bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
-                hipStream_t st) {
+// the shapes thin_wgrad takes (it launches nothing for any other)
+bool thin_wgrad_shape(const ConvShape& s, const InXform& t) {
     static const bool enabled = [] { const char* e = getenv("DVS_CONV_THIN"); return !(e && e[0] == '0'); }();
     if (!enabled || s.kh != 3 || s.kw != 3 || s.stride != 1 || s.pad != 1 || s.pad_mode != PAD_REFLECT || t.in_scale) return false;
     if (s.H < 8 || (t.x2 && ((s.H | s.W) & 1))) return false;
+    const int C1 = t.x2 != nullptr ? t.C1 : s.Cin;
+    if (C1 <= 0 || (C1 & 3) || s.Cin - C1 < 0) return false;
+    return (s.Cout == 32 && s.Cin == 96 && s.W % 32 == 0) || (s.Cout == 32 && s.Cin == 64 && s.W % 32 == 0) ||
+           (s.Cout == 16 && s.Cin == 32 && s.W % 64 == 0) || (s.Cout == 16 && s.Cin == 16 && s.W % 128 == 0);
+}
+
+bool thin_wgrad(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, const InXform& t,
+                hipStream_t st) {
+    if (!thin_wgrad_shape(s, t)) return false;
     ThinParams p{};
     p.x = x; p.dy = dy; p.y = t.aux; p.dw = dw; p.dbias = dbias;
     p.B = s.B; p.H = s.H; p.W = s.W; p.dact = t.dact;

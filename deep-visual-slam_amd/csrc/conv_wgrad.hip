@@ -30,7 +30,64 @@ struct WgradParams {
     int m_per_split;     // pixels per split, multiple of BP
     Grid3 g;             // logical grid: Cout tiles, (tap,ci) tiles, pixel splits (launched 1-D, see xcd_logical)
     int dbg;             // timing experiment (DVS_CONV_DEBUG_NOBARRIER & 4): MFMA + LDS reads only -> wrong results
+    float* part;         // null, or the slab workspace [split][tile][wave][register][lane]: every workgroup stores its accumulators
+                         // there with plain coalesced stores and wgrad_reduce_kernel adds the splits into dw in a fixed order
+    size_t part_bytes;
 };
+
+// Epilogue of the three kernels: the workgroup's BM x BN tile either goes into dw with float atomics (which execute at the
+// memory side at ~1.3 TB/s chip-wide, a fifth of the plain-store rate: MI355X_MICROARCH.md, Global float atomics) or, with a slab
+// workspace, into its own slab.  C/D map: column (k) = lane & 31, row (co) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void wgrad_store(const WgradParams& p, const f32x16 (&acc)[TM][TN], int tile, int bid_z, int co0, int k0, int wave,
+                                            int lane) {
+    const ConvShape& s = p.s;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    if (p.part) {
+        float* o = p.part + (((size_t)bid_z * (p.g.x * p.g.y) + tile) * 4 + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[((tm * TN + tn) * 16 + i) * 64] = acc[tm][tn][i];
+        return;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int kk = k0 + (wn * TN + tn) * 32 + r;
+        if (kk >= s.Ktot) continue;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                int c = cb + (i & 3) + 8 * (i >> 2);
+                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
+            }
+        }
+    }
+}
+
+// dw += sum over the splits of the slabs, in split order.  One thread per accumulator element of a tile; grid = tiles x
+// (BM x BN / 256) workgroups.  Reads and writes are coalesced (a wave's 64 lanes = two 32-column rows of dw).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Ktot, int gx,
+                                                          int tiles, int splits) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32, PER_WAVE = TM * TN * 16 * 64, PER_TILE = 4 * PER_WAVE;
+    const int tile = blockIdx.x / (PER_TILE / NT), e = (blockIdx.x % (PER_TILE / NT)) * NT + threadIdx.x;
+    const int wave = e / PER_WAVE, rem = e % PER_WAVE, reg = rem >> 6, lane = rem & 63;
+    const int tm = reg / (TN * 16), tn = (reg / 16) % TN, i = reg & 15;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const int bx = tile % gx, by = tile / gx;
+    const int c = bx * BM + (wm * TM + tm) * 32 + 4 * h + (i & 3) + 8 * (i >> 2), kk = by * BN + (wn * TN + tn) * 32 + r;
+    if (c >= Cout || kk >= Ktot) return;
+    const float* src = part + (size_t)tile * PER_TILE + e;
+    float sum = 0.f;
+    for (int z = 0; z < splits; ++z) sum += src[(size_t)z * tiles * PER_TILE];
+    dw[(size_t)c * Ktot + kk] += sum;
+}
+
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
@@ -269,20 +326,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
     }
 
     // epilogue: dW[co][k] += acc.  C/D map: column (k) = lane & 31, row (co) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int kk = k0 + (wn * TN + tn) * 32 + r;
-        if (kk >= s.Ktot) continue;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int c = cb + (i & 3) + 8 * (i >> 2);
-                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
-            }
-        }
-    }
+    wgrad_store<TM, TN, WN>(p, acc, bid_y * p.g.x + bid_x, bid_z, co0, k0, wave, lane);
     if (do_bias) {
         if (tid < BM) sBias[tid] = 0.f;
         __syncthreads();
@@ -431,20 +475,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_kernel(WgradParams p) {
         __syncthreads();
         buf ^= 1;
     }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int kk = k0 + (wn * TN + tn) * 32 + r;
-        if (kk >= s.Ktot) continue;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int c = cb + (i & 3) + 8 * (i >> 2);
-                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
-            }
-        }
-    }
+    wgrad_store<TM, TN, WN>(p, acc, bid_y * p.g.x + bid_x, bid_z, co0, k0, wave, lane);
 }
 
 // LDS-DMA weight gradient for the decoder's gathers (reflection padding, nearest-upsample + concat), once the activation
@@ -573,24 +604,11 @@ __global__ __launch_bounds__(NT) void conv_wgrad_dma_gen_kernel(WgradParams p) {
         __syncthreads();
         buf ^= 1;
     }
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int kk = k0 + (wn * TN + tn) * 32 + r;
-        if (kk >= s.Ktot) continue;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int cb = co0 + (wm * TM + tm) * 32 + 4 * h;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                int c = cb + (i & 3) + 8 * (i >> 2);
-                if (c < s.Cout) atomicAdd(p.dw + (size_t)c * s.Ktot + kk, acc[tm][tn][i]);
-            }
-        }
-    }
+    wgrad_store<TM, TN, WN>(p, acc, bid_y * p.g.x + bid_x, bid_z, co0, k0, wave, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
-void launch_cfg(WgradParams p, hipStream_t st) {
+void launch_cfg(WgradParams p, hipStream_t st, size_t* need = nullptr) {
     const int M = p.s.B * p.s.Ho * p.s.Wo;
     const int tiles = ((p.s.Cout + BM - 1) / BM) * ((p.s.Ktot + BN - 1) / BN);
     static const int wg_target = [] { const char* e = getenv("DVS_WGRAD_WGS"); return e ? atoi(e) : 1024; }();
@@ -602,6 +620,20 @@ void launch_cfg(WgradParams p, hipStream_t st) {
     dim3 grid((p.s.Cout + BM - 1) / BM, (p.s.Ktot + BN - 1) / BN, splits);
     static const int xcd_on = [] { const char* e = getenv("DVS_CONV_XCD"); return !(e && e[0] == '0') ? 1 : 0; }();
     p.g = Grid3{(int)grid.x, (int)grid.y, (int)grid.z, xcd_on};
+    const size_t slab = (size_t)grid.x * grid.y * grid.z * BM * BN * sizeof(float);
+    if (need) {                                            // workspace query: nothing is launched
+        *need = slab;
+        return;
+    }
+    if (p.part && p.part_bytes < slab) p.part = nullptr;   // (checked by the caller; never write past a short workspace)
+    struct Reduce {                                        // after whichever kernel ran: the ordered second pass
+        const WgradParams& p; dim3 g; hipStream_t st;
+        ~Reduce() {
+            if (p.part)
+                hipLaunchKernelGGL((wgrad_reduce_kernel<BM, BN, WM, WN>), dim3(g.x * g.y * (BM * BN / NT)), dim3(NT), 0, st, p.part, p.dw,
+                                   p.s.Cout, p.s.Ktot, (int)g.x, (int)(g.x * g.y), (int)g.z);
+        }
+    } reduce_after{p, grid, st};
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     prof.work(2.0 * M * p.s.Cout * k_real);
@@ -637,23 +669,26 @@ void launch_cfg(WgradParams p, hipStream_t st) {
 }
 
 template <int MODE, bool FOLD>
-void launch_mode(const WgradParams& p, hipStream_t st) {
-    if (p.s.Cout > 64) launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st);
-    else if (p.s.Cout > 32) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st);
-    else launch_cfg<32, 128, 1, 4, MODE, FOLD>(p, st);
+void launch_mode(const WgradParams& p, hipStream_t st, size_t* need = nullptr) {
+    if (p.s.Cout > 64) launch_cfg<128, 128, 2, 2, MODE, FOLD>(p, st, need);
+    else if (p.s.Cout > 32) launch_cfg<64, 128, 1, 4, MODE, FOLD>(p, st, need);
+    else launch_cfg<32, 128, 1, 4, MODE, FOLD>(p, st, need);
 }
 
 }  // namespace
 
 extern "C" {
 
-int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
-                     const dvs_conv_fusion* f, const float* y_out, int dact, void* stream) {
-    DVS_REQUIRE(x && dy && dw && d, "dvs_conv2d_wgrad: null pointer");
+// workspace != null: ordered (slab) reduction; need != null: only report the slab size of this problem (0: a path without slabs)
+static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d, const dvs_conv_fusion* f,
+                      const float* y_out, int dact, float* workspace, size_t workspace_bytes, size_t* need, void* stream) {
+    DVS_REQUIRE(need || (x && dy && dw), "dvs_conv2d_wgrad: null pointer");
+    DVS_REQUIRE(d, "dvs_conv2d_wgrad: null descriptor");
     DVS_REQUIRE((d->Cout & 3) == 0, "dvs_conv2d_wgrad: Cout must be a multiple of 4 (got %d)", d->Cout);
     DVS_REQUIRE(!dact || y_out, "dvs_conv2d_wgrad: activation gradient needs the forward output");
     WgradParams p{};
     p.x = x; p.dy = dy; p.dw = dw; p.dbias = dbias;
+    p.part = workspace; p.part_bytes = workspace_bytes;
     ConvShape& s = p.s;
     s.B = d->B; s.H = d->H; s.W = d->W; s.Cin = d->Cin; s.Cout = d->Cout;
     s.kh = d->kh; s.kw = d->kw; s.stride = d->stride; s.pad = d->pad; s.pad_mode = d->pad_mode;
@@ -675,23 +710,49 @@ int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, c
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
+    if (need) *need = 0;
     if (planar && stem_shape(s) && dact == 0 && dbias == nullptr && !p.t.in_relu) {
+        if (need) return DVS_OK;
         dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
         stem_wgrad(x, dy, dw, s, p.t.in_scale, p.t.in_shift, st);
-    } else if (!planar && thin_wgrad(x, dy, dw, dbias, s, p.t, st)) {
-        // decoder layers with 16 / 32 output channels: conv_thin.hip
+    } else if (!planar && thin_wgrad_shape(s, p.t)) {
+        // decoder layers with 16 / 32 output channels: conv_thin.hip (persistent workgroups, no slabs)
+        if (need) return DVS_OK;
+        thin_wgrad(x, dy, dw, dbias, s, p.t, st);
     } else if (planar) {
-        if (fold) launch_mode<IN_PLANAR, true>(p, st);
-        else launch_mode<IN_PLANAR, false>(p, st);
+        if (fold) launch_mode<IN_PLANAR, true>(p, st, need);
+        else launch_mode<IN_PLANAR, false>(p, st, need);
     } else if (p.t.x2) {
-        if (fold) launch_mode<IN_UPCAT, true>(p, st);
-        else launch_mode<IN_UPCAT, false>(p, st);
+        if (fold) launch_mode<IN_UPCAT, true>(p, st, need);
+        else launch_mode<IN_UPCAT, false>(p, st, need);
     } else {
-        if (fold) launch_mode<IN_NHWC, true>(p, st);
-        else launch_mode<IN_NHWC, false>(p, st);
+        if (fold) launch_mode<IN_NHWC, true>(p, st, need);
+        else launch_mode<IN_NHWC, false>(p, st, need);
     }
-    return dvs::check_launch("dvs_conv2d_wgrad");
+    return need ? DVS_OK : dvs::check_launch("dvs_conv2d_wgrad");
+}
+
+int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
+                     const dvs_conv_fusion* f, const float* y_out, int dact, void* stream) {
+    return wgrad_impl(x, dy, dw, dbias, d, f, y_out, dact, nullptr, 0, nullptr, stream);
+}
+
+size_t dvs_conv2d_wgrad_workspace(const dvs_conv_desc* d, const dvs_conv_fusion* f, int dact, int with_bias) {
+    size_t need = 0;
+    static float dummy;
+    if (wgrad_impl(nullptr, nullptr, nullptr, with_bias ? &dummy : nullptr, d, f, dact ? &dummy : nullptr, dact, nullptr, 0, &need, nullptr) != DVS_OK)
+        return 0;
+    return need;
+}
+
+int dvs_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d, const dvs_conv_fusion* f,
+                        const float* y_out, int dact, float* workspace, size_t workspace_bytes, void* stream) {
+    if (workspace) {
+        const size_t need = dvs_conv2d_wgrad_workspace(d, f, dact, dbias != nullptr);
+        DVS_REQUIRE(workspace_bytes >= need, "dvs_conv2d_wgrad_ws: workspace of %zu bytes, %zu needed", workspace_bytes, need);
+    }
+    return wgrad_impl(x, dy, dw, dbias, d, f, y_out, dact, workspace, workspace_bytes, nullptr, stream);
 }
 
 }  // extern "C"

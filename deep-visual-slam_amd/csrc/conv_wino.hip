@@ -543,6 +543,14 @@ struct WinoWgradParams {
 // The two sources of an upsample + concat layer are two launches, each adding into its own channel range of dw (CinW).
 // DACT (the thin decoder layers, whose gradient kernels apply the activation derivative themselves): dZ = dY act'(Y) is formed from
 // four more loads per tile and the bias gradient rides along.
+// 16 bytes per lane straight into LDS (64 lanes land lane-linear at M0 + IMM).  In a __device__ function of its own: called from the
+// kernel body directly, the host pass of hipcc (which has no gfx950 target feature for the 16-byte form) silently drops the
+// kernel's launch stub and the library fails to load with an undefined __device_stub__ symbol.
+template <int IMM>
+__device__ __forceinline__ void wino_dma16(__amdgpu_buffer_rsrc_t rs, float* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, IMM, 0);
+}
+
 template <int MODE, bool DACT = false>
 __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     // 128 KB: in the loop the four waves' DMA rings (RING slots of NL x 64 floats each), afterwards the accumulators of two waves
@@ -569,16 +577,22 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     const int q_begin = sp * p.pairs_per_wg + wave * per_wave;
     const int nk = max(0, min(q_begin + per_wave, npairs) - q_begin);      // pairs (= k-steps) of this wave
 
-    constexpr int NC = MODE == 2 ? 3 : 4;                  // patch rows / columns that are loaded
+    constexpr int NC = MODE == 2 ? 3 : 4;                  // patch rows / columns of one tile
     constexpr int NX = NC * NC;
     constexpr int NY = DACT ? 8 : 4;                       // dY (and Y) values of one tile
     const int Hs = MODE == 2 ? H >> 1 : H, Ws = MODE == 2 ? W >> 1 : W;      // geometry of x
-    const unsigned Cin4 = (unsigned)Cin * 4u, Cout4 = (unsigned)Cout * 4u;
-    // Addressing of one batch: address = resource base + soffset (scalar: the pair's origin) + voffset (per lane: channel, lane
-    // half, patch row and column) + the instruction's immediate (which only places the load's 256 bytes inside the LDS slot and is
-    // taken back out of the voffset).  x: the voffset counts patch rows from the row ABOVE the tile and columns from the column LEFT
-    // of the pair, so the resource starts one source row and one pixel in front of the tensor -- and another DLEAD bytes earlier for
-    // the immediates; what lies there is never read (row / column -1 are masked, mirrored or clamped).
+    const unsigned Cin4 = (unsigned)Cin * 4u, Cout4 = (unsigned)Cout * 4u, RowB = (unsigned)Ws * Cin4;
+    // One batch = the UNION of the pair's two patches, pixel by pixel: NROW rows x ROWP columns of x (4 x 6, the half-resolution
+    // source of MODE 2: 3 x 4) and the 2 x 4 pixels of dY (and Y), each pixel the 32 channels (128 bytes) of the block.  A DMA
+    // instruction moves 16 bytes per lane = 8 pixels: 3 (2) + 1 (+ 1) instructions per k-step where one dword per lane took 20 (24),
+    // and a pixel that both tiles read is fetched once.  Lane l of DMA d fetches channels 4 (l & 7) .. + 3 of pixel 8 d + (l >> 3);
+    // the LDS image of a batch is [pixel][32 channels].
+    // Addressing: address = resource base + soffset (scalar: the pair's origin) + voffset (per lane: channel quad, row and column of
+    // its pixel inside the union) + the instruction's immediate (which only places the DMA's 1 KB inside the LDS image and is taken
+    // back out of the voffset).  The voffset counts rows from the row ABOVE the pair and columns from the column LEFT of it, so the x
+    // resource starts one source row and one pixel in front of the tensor -- and another DLEAD bytes earlier for the immediates; what
+    // lies there is never read (row / column -1 are masked, mirrored or clamped).
+    constexpr int ROWP = MODE == 2 ? 4 : 6, NPIX = NC * ROWP, ND = (NPIX + 7) / 8;
     constexpr unsigned DLEAD = 4096;
     const size_t lead = (size_t)(Ws + 1) * Cin4 + DLEAD;
     const unsigned xbytes = (unsigned)((size_t)p.B * Hs * Ws * Cin4 + lead), ybytes = (unsigned)((size_t)p.B * H * W * Cout4 + DLEAD);
@@ -588,43 +602,63 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         const_cast<char*>(reinterpret_cast<const char*>(p.dy)) - DLEAD, 0, (int)ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(DACT ? p.yact : p.dy)) - DLEAD, 0, (int)ybytes, 0x00020000);
-    constexpr unsigned OOB_COL = 0x40000000u, OOB_ROW = 0x80000000u;      // marks of a masked column / row (see refresh)
+    // marks of a masked column / row: offsets stay below 2^30 (the launcher checks the tensors), so no sum of an offset and marks
+    // wraps, and every marked sum lies beyond the resource's records: the load returns 0
+    constexpr unsigned OOB_COL = 0x40000000u, OOB_ROW = 0x80000000u;
     float bsum = 0.f;                                      // DACT: my channel's sum of dZ over my tiles
 
-    // ---- per-lane column offsets: middle pairs, the first pair of a tile row, the last one (also the first when NP == 1)
-    const unsigned chx = (unsigned)(ci0 + r) * 4u + DLEAD, chy = (unsigned)(co0 + r) * 4u + DLEAD;
-    unsigned vxM[NC], vxF0, vxL[NC], vyM[2], vyL[2];
-    {
-        const int txl = 2 * (NP - 1) + h;                 // my tile in the last pair
-        const bool pad = txl >= TXn;                       // it does not exist (odd number of tiles per row)
+    // ---- per-lane voffsets of the ND + 1 DMAs.  vM: a pair in the middle of a tile row in the middle of the image; dF / dL / dT / dB:
+    // what the first / last pair of a tile row and the top / bottom tile row add to it (a mark, or the distance to the mirrored /
+    // clamped pixel).  The cases touch different lanes (column 0 vs the last columns, row 0 vs the last rows), so they simply add up.
+    const int g8 = lane >> 3, cq = lane & 7;
+    unsigned vM[ND + 1], dF[ND + 1], dL[ND + 1], dT[ND + 1], dB[ND + 1];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) {
-            if constexpr (MODE == 2) {
-                vxM[j] = (unsigned)(h + j) * Cin4 + chx;   // source column tx - 1 + j, + 1
-                const int cc = min(max(txl - 1 + j, 0), Ws - 1);      // clamped (a pad tile lands on the last column: finite)
-                vxL[j] = (unsigned)(cc - 2 * (NP - 1) + 1) * Cin4 + chx;
-            } else {
-                vxM[j] = (unsigned)(2 * h + j) * Cin4 + chx;   // image column 2 tx - 1 + j, + 1
-                const int c = 2 * txl - 1 + j;
-                if constexpr (MODE == 0) {
-                    vxL[j] = vxM[j] | ((pad || c >= W || c < 0) ? OOB_COL : 0u);
-                } else {
-                    // mirrored column; a pad tile repeats the columns of its (real) left neighbour: its dY is masked, its x only has
-                    // to be finite
-                    const int c0 = pad ? c - 2 : c;
-                    // (column W + 1 only meets a masked dY column: any finite value does, it stays right of the pair's origin - 1)
-                    const int cm = max(c0 < 0 ? -c0 : c0 >= W ? 2 * (W - 1) - c0 : c0, 4 * (NP - 1) - 1);
-                    vxL[j] = (unsigned)(cm - 4 * (NP - 1) + 1) * Cin4 + chx;
-                }
-            }
+    for (int d = 0; d < ND; ++d) {
+        const int pix = 8 * d + g8, pi = pix / ROWP, pc = pix - pi * ROWP;
+        const bool used = pix < NPIX;
+        vM[d] = used ? (unsigned)(ci0 + 4 * cq) * 4u + DLEAD + (unsigned)pi * RowB + (unsigned)pc * Cin4 - (unsigned)(d * 1024) : OOB_COL;
+        // columns: union column pc is source column cstep * txp - 1 + pc
+        constexpr int cstep = MODE == 2 ? 2 : 4;
+        const int cl = cstep * (NP - 1) - 1 + pc;          // in the last pair
+        int df = 0, dl = 0;
+        if constexpr (MODE == 0) {
+            df = pc == 0 ? (int)OOB_COL : 0;
+            dl = cl >= Ws ? (int)OOB_COL : 0;
+        } else if constexpr (MODE == 1) {
+            df = pc == 0 ? 2 * (int)Cin4 : 0;              // column -1 -> 1
+            const int cm = max(2 * (Ws - 1) - cl, cstep * (NP - 1) - 1);     // (column W + 1 only meets a masked dY column: any finite value does)
+            dl = cl >= Ws ? (cm - cl) * (int)Cin4 : 0;
+        } else {
+            df = pc == 0 ? (int)Cin4 : 0;                  // column -1 -> 0
+            dl = cl >= Ws ? (Ws - 1 - cl) * (int)Cin4 : 0;
         }
-        if constexpr (MODE == 0) vxF0 = vxM[0] | (h == 0 ? OOB_COL : 0u);
-        else vxF0 = vxM[0] + (h == 0 ? (MODE == 1 ? 2u : 1u) * Cin4 : 0u);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            vyM[b] = (unsigned)(2 * h + b) * Cout4 + chy;
-            vyL[b] = vyM[b] | ((pad || 2 * txl + b >= W) ? OOB_COL : 0u);
+        // rows: union row pi is source row rstep * ty - 1 + pi
+        constexpr int rstep = MODE == 2 ? 1 : 2;
+        const int rl = rstep * (TYn - 1) - 1 + pi;         // in the bottom tile row
+        int dt = 0, db = 0;
+        if constexpr (MODE == 0) {
+            dt = pi == 0 ? (int)OOB_ROW : 0;
+            db = rl >= Hs ? (int)OOB_ROW : 0;
+        } else if constexpr (MODE == 1) {
+            dt = pi == 0 ? 2 * (int)RowB : 0;              // row -1 -> 1
+            const int rm = max(2 * (Hs - 1) - rl, rstep * (TYn - 1) - 1);
+            db = rl >= Hs ? (rm - rl) * (int)RowB : 0;
+        } else {
+            dt = pi == 0 ? (int)RowB : 0;                  // row -1 -> 0
+            db = rl >= Hs ? (Hs - 1 - rl) * (int)RowB : 0;
         }
+        dF[d] = used ? (unsigned)df : 0u;
+        dL[d] = used ? (unsigned)dl : 0u;
+        dT[d] = used ? (unsigned)dt : 0u;
+        dB[d] = used ? (unsigned)db : 0u;
+    }
+    {   // dY (and Y): pixel (row g8 >> 2, column g8 & 3) of the pair's 2 x 4 outputs
+        const int pa = g8 >> 2, pc = g8 & 3;
+        vM[ND] = (unsigned)(co0 + 4 * cq) * 4u + DLEAD + (unsigned)(pa * W + pc) * Cout4;
+        dF[ND] = 0u;
+        dL[ND] = 4 * (NP - 1) + pc >= W ? OOB_COL : 0u;
+        dT[ND] = 0u;
+        dB[ND] = 2 * (TYn - 1) + pa >= H ? OOB_ROW : 0u;
     }
 
     // ---- the wave's position: pair q = (tb, ty, txp); everything about it is wave-uniform (scalar unit)
@@ -641,71 +675,34 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         ty = __builtin_amdgcn_readfirstlane(ty);
         txp = __builtin_amdgcn_readfirstlane(txp);
     }
-    // The fp32 MFMA holds the wave's issue for its 64 cycles (counters: MFMA + vector + scalar + memory issue cycles of a wave ADD
-    // UP to its run time at one wave per SIMD), so what counts is the NUMBER of instructions per k-step, of any kind.  The offsets of a
-    // batch therefore live in registers that only change where the pair's class changes:
-    //   cvx[i][j], cvy[a][b] -- the voffsets of the 16 (9) + 4 loads: column variant + row offset, or OOB for a row that must read
-    //   zeros (above / below the image, a k-step past the wave's range); rewritten when the wave enters a tile row (all), leaves its
-    //   first pair (column 0) or enters its last pair (all: a handful of k-steps per tile row), in branches the other k-steps skip;
-    //   sxb, syb -- the soffsets (the pair's origin): one scalar add each per k-step.
-    unsigned cvx[NC][NC], cvy[2][2], sxb = 0, syb = 0;
+    // The fp32 MFMA holds the wave's issue for its 64 cycles (counters: the MFMA, vector, scalar and memory issue cycles of a wave ADD
+    // UP to its run time at one wave per SIMD), so what counts is the NUMBER of instructions per k-step, of any kind.  The voffsets of
+    // a batch therefore live in registers (cv) that are only rewritten where the pair's class changes -- entering a tile row, leaving
+    // its first pair, entering its last pair: a handful of k-steps per tile row, in a branch the others skip -- and the soffsets (the
+    // pair's origin) take one scalar add each per k-step.
+    unsigned cv[ND + 1], sxb = 0, syb = 0;
     int kq = 0;                                            // k-step (of this wave) at (tb, ty, txp)
     auto origin = [&]() __attribute__((always_inline)) {
         if constexpr (MODE == 2) sxb = (unsigned)((tb * Hs + ty) * Ws + 2 * txp) * Cin4;
         else sxb = (unsigned)((tb * H + 2 * ty) * W + 4 * txp) * Cin4;
         syb = (unsigned)((tb * H + 2 * ty) * W + 4 * txp) * Cout4;
     };
-    // columns [J0, J1) of cvx (and, with WITH_Y, cvy) for the pair at (ty, txp).  A value is (column variant: per lane) + (row term:
-    // scalar).  Masked columns carry OOB_COL, masked rows add OOB_ROW: with offsets below 2^30 (the launcher checks the tensors) no sum
-    // wraps, and every marked sum lies beyond the resource's records: the load returns 0.
-    auto refresh = [&](auto j0_tag, auto j1_tag, auto y_tag) __attribute__((always_inline)) {
-        constexpr int J0 = decltype(j0_tag)::value, J1 = decltype(j1_tag)::value;
-        constexpr bool WITH_Y = decltype(y_tag)::value;
-        const bool live = kq < nk, first = txp == 0, last = txp == NP - 1;
-        const int oy = 2 * ty;
-        unsigned col[NC];
+    auto refresh = [&]() __attribute__((always_inline)) {
+        const bool live = kq < nk, first = txp == 0, last = txp == NP - 1, top = ty == 0, bot = ty == TYn - 1;
 #pragma unroll
-        for (int j = J0; j < J1; ++j) {
-            const unsigned m = vxM[j], l = vxL[j], f = vxF0;      // values first, then the selects: a ?: over the captured variables
-            col[j] = last ? l : (j == 0 && first) ? f : m;        // themselves selects between their ADDRESSES inside the closure
+        for (int d = 0; d <= ND; ++d) {
+            const unsigned m = vM[d], f = dF[d], l = dL[d];     // values first, then the selects: a ?: over the captured variables
+            cv[d] = m + (first ? f : 0u) + (last ? l : 0u);     // themselves selects between their ADDRESSES inside the closure
         }
+        if (top || bot || !live) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            // patch row i: its distance (in source rows) from the row above the tile, or the mark of a row that reads zeros
-            int rofs;
-            bool ok = live;
-            if constexpr (MODE == 0) {
-                rofs = i;
-                ok = ok & (oy - 1 + i >= 0) & (oy - 1 + i < H);
-            } else if constexpr (MODE == 1) {
-                const int rw = oy - 1 + i, rm = max(rw < 0 ? -rw : rw >= H ? 2 * (H - 1) - rw : rw, 0);
-                rofs = rm - (oy - 1);
-            } else {
-                rofs = min(max(ty - 1 + i, 0), Hs - 1) - (ty - 1);
-            }
-            const unsigned rterm = ((unsigned)(rofs * Ws) * Cin4) | (OOB_ROW & (0u - (unsigned)!ok));
-#pragma unroll
-            for (int j = J0; j < J1; ++j) cvx[i][j] = col[j] + (rterm - (unsigned)((i * NC + j) * 256));
-        }
-        if constexpr (WITH_Y) {
-            unsigned cy[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const unsigned m = vyM[b], l = vyL[b];
-                cy[b] = last ? l : m;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const bool ok = live & (oy + a < H);
-                const unsigned rterm = ((unsigned)(a * W) * Cout4) | (OOB_ROW & (0u - (unsigned)!ok));
-#pragma unroll
-                for (int b = 0; b < 2; ++b) cvy[a][b] = cy[b] + (rterm - (unsigned)((2 * a + b) * 256));
+            for (int d = 0; d <= ND; ++d) {
+                const unsigned t = dT[d], b = dB[d];
+                cv[d] += (top ? t : 0u) + (bot ? b : 0u);
+                cv[d] |= live ? 0u : OOB_ROW;              // a k-step past the wave's range reads zeros
             }
         }
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using IN = std::integral_constant<int, NC>;
     // to the next pair (an interior k-step: four scalar adds and the compares that fall through)
     auto advance = [&]() __attribute__((always_inline)) {
         ++kq;
@@ -721,39 +718,29 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
             }
             origin();
         }
-        if (txp == 0 || txp == NP - 1 || kq == nk || NP <= 2) refresh(I0{}, IN{}, std::true_type{});      // entering a row / its last pair
-        else if (txp == 1) refresh(I0{}, I1{}, std::false_type{});                                          // leaving the first pair
+        if (txp <= 1 || txp == NP - 1 || kq == nk) refresh();      // entering a tile row, leaving its first pair, entering its last
     };
 
-    // One batch = the 4 (8) dY (and Y) values of my tile, then its 16 (9) patch pixels, as LDS-DMA loads (buffer_load_dword ... lds:
-    // 64 lanes x 4 bytes land lane-linear at M0 + immediate): nothing in flight occupies a register, so no loop-carried register
-    // set exists for the allocator to copy around (round 2's kernel paid 20 staging moves per k-step to keep its in-flight
-    // registers fixed; left to itself the allocator put such copies -- behind a vmcnt(0) -- at the loop's back edge).  The loads of a
-    // group share one M0 (the slot's base); the immediate that separates them is taken back out of the voffsets (refresh).
-    constexpr int NL = NX + NY, RING = 4;                  // loads per k-step; ring slots = prefetch distance (3 k-steps) + 1
-    float* const ring = sMem + wave * (RING * NL * 64);
-    using lds_t = __attribute__((address_space(3))) void*;
+    constexpr int XS = ND * 8, SLOTF = (XS + 8 + (DACT ? 8 : 0)) * 32, NDMA = ND + 1 + (DACT ? 1 : 0), RING = 4;
+    float* const ring = sMem + wave * (RING * SLOTF);     // ring slots = prefetch distance (3 k-steps) + 1
     auto issue_dma = [&](int slot) __attribute__((always_inline)) {
-        float* const dst = ring + slot * (NL * 64);
-#define WINO_DMA_Y(A, B2)                                                                                                       \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_t)dst, 4, cvy[A][B2], syb, (2 * A + B2) * 256, 0);                          \
-    if constexpr (DACT) __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_t)(dst + 4 * 64), 4, cvy[A][B2], syb, (2 * A + B2) * 256, 0);
-        WINO_DMA_Y(0, 0) WINO_DMA_Y(0, 1) WINO_DMA_Y(1, 0) WINO_DMA_Y(1, 1)
-#undef WINO_DMA_Y
-#define WINO_DMA_X(I, J) \
-    if constexpr (I < NC && J < NC) __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_t)(dst + NY * 64), 4, cvx[I][J], sxb, (I * NC + J) * 256, 0);
-#define WINO_DMA_XROW(I) WINO_DMA_X(I, 0) WINO_DMA_X(I, 1) WINO_DMA_X(I, 2) WINO_DMA_X(I, 3)
-        WINO_DMA_XROW(0) WINO_DMA_XROW(1) WINO_DMA_XROW(2) WINO_DMA_XROW(3)
-#undef WINO_DMA_XROW
-#undef WINO_DMA_X
+        float* const dst = ring + slot * SLOTF;
+        wino_dma16<0>(yr, dst + XS * 32, cv[ND], syb);
+        if constexpr (DACT) wino_dma16<0>(ar, dst + (XS + 8) * 32, cv[ND], syb);
+        wino_dma16<0>(xr, dst, cv[0], sxb);
+        wino_dma16<1024>(xr, dst, cv[1], sxb);
+        if constexpr (ND > 2) wino_dma16<2048>(xr, dst, cv[ND > 2 ? 2 : 0], sxb);
     };
-    // (the lane's read address of the NEXT k-step is formed behind the transform, so that the LDS reads depend on nothing inside the
-    // MFMA block they are issued in)
+    // my values of a batch: the lane's tile starts (2 h) -- MODE 2: h -- pixels into the union's rows
+    const int bx = (MODE == 2 ? h : 2 * h) * 32 + r, by = 2 * h * 32 + r;
     auto read_slot = [&](const float* src, float (&xv)[NX], float (&yv)[NY]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int e = 0; e < NY; ++e) yv[e] = src[e * 64];
+        for (int e = 0; e < 4; ++e) {
+            yv[e] = src[by + (XS + 4 * (e >> 1) + (e & 1)) * 32];
+            if constexpr (DACT) yv[4 + e] = src[by + (XS + 8 + 4 * (e >> 1) + (e & 1)) * 32];
+        }
 #pragma unroll
-        for (int e = 0; e < NX; ++e) xv[e] = src[(NY + e) * 64];
+        for (int e = 0; e < NX; ++e) xv[e] = src[bx + ((e / NC) * ROWP + (e % NC)) * 32];
     };
     // v = B^T d B;  pm = |A| dY |A|^T: rows (1,0), (1,1), (1,-1), (0,1) -- the true A has (0,-1) as its last row, i.e. components
     // (3, l) and (i, 3) carry a factor -1 each that the epilogue applies (kWgradSign)
@@ -810,7 +797,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     float tx[NX], ty_[NY], v[16], pm[16];
 #define WINO_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
     origin();
-    refresh(I0{}, IN{}, std::true_type{});
+    refresh();
     int slot_w = 0;                                        // slot the next batch goes to
 #pragma unroll
     for (int j = 0; j < RING - 1; ++j) {                   // k-steps 0, 1, 2
@@ -818,11 +805,11 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         issue_dma(slot_w);
         slot_w = (slot_w + 1) & (RING - 1);
     }
-    WINO_WAIT_VMCNT((RING - 2) * NL);                      // k-step 0 has landed
-    read_slot(ring + lane, tx, ty_);
+    WINO_WAIT_VMCNT((RING - 2) * NDMA);                    // k-step 0 has landed
+    read_slot(ring, tx, ty_);
     transform(tx, ty_, v, pm);
     int slot_r = 1;                                        // slot of k-step k+1
-    const float* rd = ring + slot_r * (NL * 64) + lane;
+    const float* rd = ring + slot_r * SLOTF;
     for (int k = 0; k < nk; ++k) {
         advance();                                         // (at the head of the step: behind the transform the compiler sank the
         __builtin_amdgcn_sched_barrier(0);                 // transform -- and with it the LDS reads -- below advance's branches)
@@ -832,10 +819,10 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);     // VMEM read (the DMAs)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read (the DMAs)
         }
         __builtin_amdgcn_sched_barrier(0);
-        WINO_WAIT_VMCNT((RING - 2) * NL);
+        WINO_WAIT_VMCNT((RING - 2) * NDMA);
         read_slot(rd, tx, ty_);
 #pragma unroll
         for (int q = 6; q < 16; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(pm[q], v[q], acc[q], 0, 0, 0);
@@ -848,7 +835,7 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         transform(tx, ty_, v, pm);
         slot_w = (slot_w + 1) & (RING - 1);
         slot_r = (slot_r + 1) & (RING - 1);
-        rd = ring + slot_r * (NL * 64) + lane;
+        rd = ring + slot_r * SLOTF;
     }
     __builtin_amdgcn_sched_barrier(0);
     WINO_WAIT_VMCNT(0);                                    // the batches past the end (they read zeros) must not land in sR

@@ -235,6 +235,14 @@ int dvs_conv2d_dgrad_res(const float* dy, const float* wt, float* dx, const dvs_
                          int dact, float* dx_skip, int C1, const float* residual, void* stream);
 int dvs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d,
                      const dvs_conv_fusion* f, const float* y_out, int dact, void* stream);
+/*   Ordered form (ABI 7): with a slab workspace of >= dvs_conv2d_wgrad_workspace(...) bytes every workgroup of the split-K implicit
+ *   GEMM stores its partial tile with plain stores and a second kernel adds the splits into dw in split order -- no float atomics
+ *   on dw (they run at a fifth of the plain-store rate on this chip and make the result depend on timing).  The stem and the thin
+ *   full-resolution decoder layers have no slab path (workspace size 0: the call behaves like dvs_conv2d_wgrad); a bias gradient
+ *   (dbias) still rides on atomics.  workspace = NULL: dvs_conv2d_wgrad. */
+size_t dvs_conv2d_wgrad_workspace(const dvs_conv_desc* d, const dvs_conv_fusion* f, int dact, int with_bias);
+int dvs_conv2d_wgrad_ws(const float* x, const float* dy, float* dw, float* dbias, const dvs_conv_desc* d, const dvs_conv_fusion* f,
+                        const float* y_out, int dact, float* workspace, size_t workspace_bytes, void* stream);
 
 /* Narrow output heads (Cout in {1,2,6,8}, Cin % 4 == 0, stride 1, "same" size: 2*pad == k-1) on the vector
  * ALUs: DepthNet's dispconv layers (model/depthnet.py:57-58,86-88) and PoseNet's last 1x1

@@ -358,7 +358,8 @@ def test_amp_branch_of_train_mono_step(gpu_device, fused):
             seen.append({k: float(v) for k, v in losses.items()})
             assert outputs[("disp", 0)].dtype == torch.float32
         torch.cuda.synchronize()
-        weights = {k: v.detach().cpu().clone() for k, v in list(dn.named_parameters()) + list(pn.named_parameters())}
+        named = [("d." + k, v) for k, v in dn.named_parameters()] + [("p." + k, v) for k, v in pn.named_parameters()]
+        weights = {k: v.detach().cpu().clone() for k, v in named}
         results.append((seen, weights))
         if use_amp:
             # third step with a poisoned gradient: no weight may move, the scale halves (GradScaler's backoff)
@@ -366,18 +367,18 @@ def test_amp_branch_of_train_mono_step(gpu_device, fused):
             p_bad = dict(dn.named_parameters())["decoder.9.conv.conv.weight"]
 
             def poison():
-                p_bad.grad.view(-1)[0] = float("inf")
+                p_bad.grad[0, 0, 0, 0] = float("inf")         # (.grad is a [Cout][kh][kw][Cin]-stored view of the arena)
 
             learner._noise = noises[2]
             _train_mono_step(learner, optimizer, dict(sample), True, scaler, poison)
             torch.cuda.synchronize()
-            for k, v in list(dn.named_parameters()) + list(pn.named_parameters()):
+            for k, v in named:
                 assert torch.equal(v.detach().cpu(), weights[k]), k
             assert scaler.get_scale() == 0.5 * scale0
             # and the step after that trains again
             _train_mono_step(learner, optimizer, dict(sample), True, scaler)
             torch.cuda.synchronize()
-            moved = max(float((v.detach().cpu() - weights[k]).abs().max()) for k, v in dn.named_parameters() if ".fc." not in k)
+            moved = max(float((v.detach().cpu() - weights[k]).abs().max()) for k, v in named if ".fc." not in k)
             assert 0.0 < moved <= 2.0 * LR
     (l_a, w_a), (l_b, w_b) = results
     for k in l_a[0]:
