@@ -44,6 +44,7 @@ struct WinoParams {
     int act;               // epilogue activation code of conv_common.h (0 none, 1 ReLU, 2 ELU)
     const float* res;      // null, or a tensor of y's shape added to the convolution (before bias / activation)
     int stat_mask, stat_stride;   // statistics slots: workgroup w adds into stats + (w & stat_mask) * stat_stride (0, 0: one copy)
+    int ksplit, grid0;            // KSPLIT kernels: the input channels are dealt to `ksplit` workgroups per tile block (grid0 each)
 };
 
 // w [Cout][3][3][Cin] -> u [Cin][4][Cout][4] (flip = 0), or the data-gradient filter: u [Cout][4][Cin][4] from w rotated 180 degrees
@@ -161,7 +162,10 @@ __global__ __launch_bounds__(NT) void wino_weights_batch_kernel(const WinoEntry*
 // Three LDS buffers: the one written in chunk c was last read two barriers ago.
 // GEN: 0 = zero-padded 'same' convolution of one tensor (the BasicBlock layers); 1 = general gather from one source (reflection,
 // upsample, output size / origin); 2 = general gather from two concatenated sources.
-template <int WT, int WC, int DBG = 0, int GEN = 0, bool RES = false>     // RES: y += res (same shape); DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
+// KSPLIT: the workgroups of a tile block split the input channels and ADD their outputs into a zero-filled y with float atomics
+// (no bias / activation / statistics in the kernel; the residual rides with split 0): layer 4 at batch 12 is 120 workgroups of 256
+// k-steps for 256 CUs -- as 240 workgroups of 128 it keeps every CU busy (launch_wino decides).
+template <int WT, int WC, int DBG = 0, int GEN = 0, bool RES = false, bool KSPLIT = false>     // RES: y += res (same shape); DBG (tools/wino_bench.py): 1 no U loads, 2 no A reads, 4 no staging, 8 no barrier in the loop, 16 no epilogue
 __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     static_assert(WT * WC == 4 && (WT == 1 || WT == 2), "four waves");
     constexpr int MT = 32 * WT, CK = 8, CKP = CK + 4, KH = 4, VEC = WT, PP = CK / VEC;
@@ -178,7 +182,9 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     const int TXn = (Wo + 1) >> 1, TYn = (Ho + 1) >> 1, ntiles = p.B * TYn * TXn;
     // XCD-aware order: workgroups that share input tiles (the channel blocks of one tile block) run on the same XCD / L2
     const int nb = p.tiles_x, ntb = p.tiles_y;                        // channel blocks, tile blocks
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ks = KSPLIT ? (int)blockIdx.x / p.grid0 : 0;           // my share of the input channels
+    const int bid = KSPLIT ? (int)blockIdx.x - ks * p.grid0 : (int)blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
     const int cb = slot % nb, tb = (slot / nb) * 8 + xcd;
     if (tb >= ntb) return;
     const int tile0 = tb * MT;
@@ -251,8 +257,9 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         }
     }
     using vec_t = typename std::conditional<VEC == 2, f32x2, float>::type;
+    const int nchunk = KSPLIT ? Cin / CK / p.ksplit : Cin / CK, chunk0 = ks * nchunk;      // my chunks: [chunk0, chunk0 + nchunk)
     auto load_pixel = [&](int chunk, int i, int j) -> vec_t {
-        int soff = chunk * CK * 4;
+        int soff = (chunk0 + chunk) * CK * 4;
         __amdgpu_buffer_rsrc_t rs = xr;
         unsigned off = st_off[i][j];
         if constexpr (GEN == 2) {                         // chunk-uniform choice of the source
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     const int u_kstride = 4 * Cout * 16, u_qstride = Cout * 16;       // bytes per channel, per component row
     f32x4 un[4];
     auto load_u = [&](int chunk, int j) {
-        const int soff = (chunk * CK + j) * u_kstride;
+        const int soff = ((chunk0 + chunk) * CK + j) * u_kstride;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // (bit_cast of the builtin's own vector type: an implicit conversion to an ext_vector_type splats element 0)
@@ -311,7 +318,6 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     };
     load_u(0, 0);
 
-    const int nchunk = Cin / CK;
     vec_t stg[4][4], tt[4][4];
     f32x4 a[16], an[16];
     auto read_a = [&](int buf, f32x4 (&dst)[16]) {
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * Ho * Wo * Cout * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(RES ? p.res : p.y), 0,
                                                                          RES ? (int)((size_t)p.B * Ho * Wo * Cout * 4) : 0, 0x00020000);
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = !KSPLIT && p.stats != nullptr;
     int tinfo[16];
     unsigned tbase[16];
 #pragma unroll
@@ -452,7 +458,11 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
                 for (int c2 = 0; c2 < 2; ++c2) {
                     float yv = y[a2][c2][e];
                     const unsigned off = v[a2][c2] ? base + a2 * row_b + c2 * col_b : 0xC0000000u;
-                    if constexpr (RES) yv += rv[i + e][2 * a2 + c2];
+                    if constexpr (RES) yv += (KSPLIT && ks != 0) ? 0.f : rv[i + e][2 * a2 + c2];
+                    if constexpr (KSPLIT) {
+                        if (v[a2][c2]) atomicAdd(p.y + (off >> 2), yv);
+                        continue;
+                    }
                     float z = fmaxf(yv + bv, lo);
                     if constexpr (GEN != 0) {
                         if (p.act == kActElu) z = yv + bv > 0.f ? yv + bv : expm1f(yv + bv);
@@ -477,7 +487,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
             }
         }
     }
-    if (p.stats) {
+    if (want_stats) {
         // One workgroup per CU: a workgroup's last act is these atomics, and its CU stays occupied until they are acknowledged.  Thousands
         // of workgroups adding to the SAME 2 x Cout addresses serialise in the L2 (~35 ns each: +120 us on a 140 us layer-1 launch at
         // batch 24), so the workgroups spread over several copies of the table that the BatchNorm kernel adds up (dvs_bn_fwd_slots).
@@ -919,6 +929,42 @@ __global__ __launch_bounds__(NT) void wino_wgrad_reduce_kernel(const float* __re
     dw[((size_t)co * 9 + tap) * CinW + ci] += s;
 }
 
+// Helpers of the K-split launches: zero fill of y, and the BatchNorm statistics (sum, sum of squares per channel and group) of the
+// finished y -- what the single-launch kernel takes in its epilogue.  One workgroup per slab of rows, float4 per lane, one atomic
+// per channel and workgroup into copy 0 of the statistics table.
+__global__ __launch_bounds__(NT) void wino_zero_kernel(f32x4* __restrict__ y, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n4; i += (size_t)gridDim.x * NT) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(NT) void wino_stats_kernel(const float* __restrict__ y, float* __restrict__ stats, int rows, int C, int rows_per_wg,
+                                                        int split_row, int groups) {
+    __shared__ float sAcc[2][2][1024];                     // [group][sum / sumsq][channel], C <= 1024
+    const int c4n = C >> 2, lanes_rows = NT / c4n;         // C / 4 divides 256 (the launcher checks)
+    const int c4 = threadIdx.x % c4n, rsub = threadIdx.x / c4n;
+    for (int i = threadIdx.x; i < 4 * 1024; i += NT) (&sAcc[0][0][0])[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, q[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int rw = r0 + rsub; rw < r1; rw += lanes_rows) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)rw * C + 4 * c4);
+        const int g = rw >= split_row ? 1 : 0;
+        s[g] += v;
+        q[g] += v * v;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&sAcc[g][0][4 * c4 + e], s[g][e]);
+            atomicAdd(&sAcc[g][1][4 * c4 + e], q[g][e]);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < groups * 2 * C; i += NT) {
+        const int g = i / (2 * C), k = (i / C) & 1, c = i % C;
+        const float v = sAcc[g][k][c];
+        if (v != 0.f) atomicAdd(stats + (size_t)g * 2 * C + k * C + c, v);
+    }
+}
+
 template <int WT, int WC, int GEN = 0>
 void launch_wino(WinoParams& p, hipStream_t st) {
     const int Ho = GEN ? p.Ho : p.H, Wo = GEN ? p.Wo : p.W;
@@ -930,6 +976,28 @@ void launch_wino(WinoParams& p, hipStream_t st) {
         static const int dbg = getenv("DVS_WINO_DBG") ? atoi(getenv("DVS_WINO_DBG")) : 0;
 #define WINO_DBG_CASE(D) \
     case D: hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, D>), dim3((unsigned)grid), dim3(NT), 0, st, p); break;
+        // K split (see the kernel): wide layers whose tile blocks fill less than ~0.6 of the CUs, no bias / activation in the epilogue
+        static const bool ks_on = [] { const char* e = getenv("DVS_WINO_KSPLIT"); return !(e && e[0] == '0'); }();
+        if constexpr (WT == 1 && WC == 4) {
+            const int nchunk = p.Cin / 8;
+            if (ks_on && !dvs::deterministic() && dbg == 0 && !p.bias && !p.relu && p.act == 0 && grid <= 152 && nchunk % 4 == 0 && nchunk >= 16 &&
+                (p.Cout & 3) == 0 && 256 % (p.Cout >> 2) == 0 && p.Cout <= 1024) {
+                p.ksplit = 2;
+                p.grid0 = (int)grid;
+                const size_t n4 = (size_t)p.B * p.H * p.W * p.Cout / 4;
+                hipLaunchKernelGGL(wino_zero_kernel, dim3(256), dim3(NT), 0, st, reinterpret_cast<f32x4*>(p.y), n4);
+                if (p.res) hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, 0, true, true>), dim3((unsigned)grid * 2), dim3(NT), 0, st, p);
+                else hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, 0, false, true>), dim3((unsigned)grid * 2), dim3(NT), 0, st, p);
+                if (p.stats) {
+                    const int rows = p.B * p.H * p.W, rpw = 128;
+                    const int groups = p.stat_split == 0x7fffffff ? 1 : 2;
+                    const int split_row = groups == 2 ? p.stat_split * p.H * p.W : 0x7fffffff;
+                    hipLaunchKernelGGL(wino_stats_kernel, dim3((unsigned)((rows + rpw - 1) / rpw)), dim3(NT), 0, st, p.y, p.stats, rows, p.Cout,
+                                       rpw, split_row, groups);
+                }
+                return;
+            }
+        }
         if (p.res) {
             hipLaunchKernelGGL((wino_fwd_kernel<WT, WC, 0, 0, true>), dim3((unsigned)grid), dim3(NT), 0, st, p);
             return;

@@ -41,7 +41,7 @@ def _rel(a, ref):
     return float((a.double() - ref).abs().max() / ref.abs().max())
 
 
-SHAPES = [(2, 64, 64, 120, 160), (2, 128, 128, 60, 80), (2, 256, 256, 30, 40), (2, 512, 512, 15, 20),      # encoder, 480x640
+SHAPES = [(2, 64, 64, 120, 160), (2, 128, 128, 60, 80), (2, 256, 256, 30, 40), (2, 512, 512, 15, 20), (12, 512, 512, 15, 20),      # encoder, 480x640 (the 512-channel ones take the K split)
           (4, 64, 128, 13, 27), (2, 128, 64, 1, 5), (2, 64, 192, 7, 1), (6, 80, 96, 6, 6), (1, 64, 64, 2, 2)]
 
 
@@ -409,7 +409,8 @@ def test_statistics_spread_over_slots(B, c, h, w, groups):
     st = torch.zeros(16, groups, 2, c, device="cuda")
     y = DC.conv3x3_wino(x, wt, st, groups, stat_slots=16)
     assert _rel(y, y64) < TOL
-    assert int((st.abs().sum((1, 2, 3)) > 0).sum()) > 1            # more than one copy was used
+    if B * h * w >= 4 * 60 * 80:                                    # (small launches take the K split: statistics by a pass of their own, copy 0)
+        assert int((st.abs().sum((1, 2, 3)) > 0).sum()) > 1        # more than one copy was used
     parts = y64.chunk(groups, 0)
     ref = torch.stack([torch.stack([p.sum((0, 2, 3)), (p * p).sum((0, 2, 3))]) for p in parts])
     tot = st.double().sum(0)
