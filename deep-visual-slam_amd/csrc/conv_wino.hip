@@ -326,10 +326,22 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     };
     // prologue: chunks 0 and 1 into buffers 0 and 1 (both loads in flight together), chunk 2 loaded (chunks past the end
     // re-read the last one; never used)
+    f32x16 acc[16];
     {
         vec_t stg1[4][4];
         load_stage(0, stg);
         load_stage(1, stg1);                              // nchunk >= 2
+        // the 256 accumulator writes (0.5 us of issue) go HERE, under the flight time of the first two chunks -- left to itself the
+        // compiler put half of them in front of these loads and the other half in front of the first MFMA
+        // (asm: a plain `= 0.f` is a rematerialisable constant that the register allocator sinks to the first MFMA)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float z;
+                asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+                acc[q][i] = z;
+            }
 #pragma unroll
         for (int k = 0; k < 4; ++k) transform_piece(k, 0, stg, tt);
         load_stage(min(2, nchunk - 1), stg);
@@ -338,11 +350,6 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     }
     __syncthreads();
     read_a(0, a);
-    f32x16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
     // one chunk: MFMAs of chunk ch from `ac`; `anx` <- A operands of chunk ch + 1.  Every k-step is one scheduling region in which
     // the next k-step's B operands, a quarter of the A reads, a transform piece and a third of the stage loads are interleaved
@@ -796,10 +803,6 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
     };
 
     f32x16 acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
 
     // Step k:  DMA of k-step k+3 -> the slot that held k-1 (read and transformed during step k-2)  |  the first MFMAs of k  |  wait
     // until the batch of k+1 has landed (two younger batches stay in flight)  |  its 20 values LDS -> registers  |  the other MFMAs  |
@@ -815,6 +818,16 @@ __global__ __launch_bounds__(NT, 1) void wino_wgrad_kernel(WinoWgradParams p) {
         issue_dma(slot_w);
         slot_w = (slot_w + 1) & (RING - 1);
     }
+    // the 256 accumulator writes (0.5 us of issue) under the flight time of the first batches (asm: a plain `= 0.f` is a
+    // rematerialisable constant that the register allocator sinks to the first MFMA)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float z;
+            asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z));
+            acc[q][i] = z;
+        }
     WINO_WAIT_VMCNT((RING - 2) * NDMA);                    // k-step 0 has landed
     read_slot(ring, tx, ty_);
     transform(tx, ty_, v, pm);
