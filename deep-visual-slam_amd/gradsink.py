@@ -102,12 +102,15 @@ class StreamSet:
         _sets.add(self)
 
     # ---- side streams
-    def side_stream(self):
-        """Side stream paired with the current stream, or None when disabled.  Called from backward code: the first call of
-        a backward pass queues the end-of-pass fence."""
+    def side_stream(self, queue=True):
+        """Side stream paired with the current stream, or None when disabled (or when the current stream is itself a side
+        stream).  Called from backward code: the first call of a backward pass queues the end-of-pass fence; forward code that
+        wants a branch to run beside the main chain (the BasicBlock's 1x1 downsample convolution) passes queue=False."""
         if not _enabled:
             return None
         cur = torch.cuda.current_stream()
+        if any(cur.cuda_stream == sd.cuda_stream for _, sd in self.side.values()):
+            return None                           # already ON a side stream (a forward branch that ran there): no side stream of a side stream
         key = (cur.device_index, cur.cuda_stream)
         pair = self.side.get(key)
         if pair is None:
@@ -118,7 +121,8 @@ class StreamSet:
                         shared = side
             pair = self.side[key] = (cur, shared if shared is not None
                                      else torch.cuda.Stream(device=cur.device, priority=_priority("side")))
-        self.queue_end_fence()
+        if queue:
+            self.queue_end_fence()
         return pair[1]
 
     def queue_end_fence(self):

@@ -211,11 +211,29 @@ def _conv_bn_act_ds_passthrough(x, weight, bn, stride, padding, relu, residual, 
             or not _bn.supported_c(weight.shape[0], bn) or not _bn.supported_c(res[0].shape[0], res[1])):
         return conv_bn_act(x, weight, bn, stride, padding, relu, residual, res), residual
     G = _batch_groups
+    # The 1x1 downsample convolution is a few dozen small workgroups (18 - 50 us that leave most of the chip idle) and depends on
+    # the block input only: it runs on the network's side stream BESIDE conv2 -- and, because autograd replays a node on the stream of
+    # its forward, its data gradient runs beside conv2's in the backward pass too (DVS_DS_STREAM=0: in line).
+    from . import gradsink
+    side = gradsink.active().side_stream(queue=False) if _DS_STREAM else None
+    if side is None:
+        y, st = _conv.conv2d(x, weight, None, stride, padding, want_stats=G | _conv.STATS_SLOTTED)
+        yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G | _conv.STATS_SLOTTED, passthrough=True)
+        return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G), ra
+    cur = torch.cuda.current_stream()
+    side.wait_stream(cur)                                  # the block input, the weights, the zero-filled statistics scratch
+    with torch.cuda.stream(side):
+        yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G | _conv.STATS_SLOTTED, passthrough=True)
+    residual.record_stream(side)
     y, st = _conv.conv2d(x, weight, None, stride, padding, want_stats=G | _conv.STATS_SLOTTED)
-    yd, std, ra = _conv.conv2d(residual, res[0], None, res[2], 0, want_stats=G | _conv.STATS_SLOTTED, passthrough=True)
+    cur.wait_stream(side)
+    for t in (yd, std):
+        if isinstance(t, torch.Tensor):
+            t.record_stream(cur)                           # allocated under the side stream, consumed here
     return _bn.bn_act(y, bn, st, relu, residual=yd, res_bn=res[1], res_stats=std, groups=G), ra
 
 
+_DS_STREAM = os.environ.get("DVS_DS_STREAM", "0") == "1"      # measured: 24.35-24.43 ms/step with it against 24.18-24.23 without (profiles/r03_b_ds_stream_ab.txt): off
 _STEM_TAIL = os.environ.get("DVS_STEM_TAIL", "1") != "0"
 
 
