@@ -43,7 +43,8 @@ struct AttnParams {
 __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
     __shared__ float sO[4][HD][QT + 1];        // per wave: O^T (dims x queries); +1: conflict-free transposed read
     __shared__ float sM[4][QT], sL[4][QT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // (scalar: the per-tile buffer resources derive from it)
     const int q0 = blockIdx.x * QT, head = blockIdx.y, b = blockIdx.z;
     const int N = p.N, C = p.heads * HD;
     const size_t row = (size_t)3 * C;                                   // floats between consecutive tokens
@@ -67,26 +68,41 @@ __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + KT - 1) / KT;
+    // K / V through buffer resources that end with this image's last token: a key row past N reads zeros from the range check (its
+    // score is masked below, its V row multiplies p = 0), and a lane's 8 + 32 offsets are loop invariant -- the tile moves the
+    // resource's base.  (Round 2 clamped and multiplied every row index per load: ~160 vector instructions of address arithmetic per tile
+    // beside 64 fp32 MFMAs that run on the same vector pipe.)
+    const unsigned rowb = (unsigned)row * 4u, kvbytes = (unsigned)((size_t)N * row * 4 - (size_t)(C + head * HD) * 4);
+    unsigned koff[8], voff[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) koff[j] = (unsigned)r * rowb + (unsigned)(4 * (2 * j + h)) * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            voff[0][j][u] = (unsigned)(8 * j + 4 * h + u) * rowb + (unsigned)r * 4u;
+            voff[1][j][u] = voff[0][j][u] + 128u;
+        }
     for (int t = wave; t < ntiles; t += 4) {
         const int k0 = t * KT;
+        // the tile's resources start at its first key row (scalar arithmetic); the range check looks at the voffset alone
+        const unsigned tb = (unsigned)k0 * rowb;
+        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(K)) + tb, 0, (int)(kvbytes - tb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(V)) + tb, 0, (int)(kvbytes - (unsigned)C * 4u - tb), 0x00020000);
         // ---- S^T = K Q^T : A operand = key row k0 + r, dims 4 (2 j + h) .. + 3
         f32x4 kv[8];
-        {
-            const int ki = min(k0 + r, N - 1);
-            const float* kp = K + (size_t)ki * row;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kv[j] = *reinterpret_cast<const f32x4*>(kp + 4 * (2 * j + h));
-        }
+        for (int j = 0; j < 8; ++j) kv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, koff[j], 0, 0));
         // V^T operand: A[m = dim][k = key]: lane (r, h) of step j needs V[k0 + 8 j + 4 h + u][32 dt + r], u = 0..3
         float vv[2][4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ki = min(k0 + 8 * j + 4 * h + u, N - 1);
-                const float* vp = V + (size_t)ki * row;
-                vv[0][j][u] = vp[r];
-                vv[1][j][u] = vp[32 + r];
+                vv[0][j][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vr, voff[0][j][u], 0, 0));
+                vv[1][j][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vr, voff[1][j][u], 0, 0));
             }
         }
         f32x16 s;
@@ -98,13 +114,16 @@ __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
             for (int u = 0; u < 4; ++u) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[j][u], qv[j][u], s, 0, 0, 0);
         }
         // s[i]: key k0 + (i & 3) + 8 (i >> 2) + 4 h, query q0 + r.  Keys beyond N do not exist.
+        if (k0 + KT > N) {                                     // (wave-uniform: only the last tile has such keys)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                s[i] = key < N ? s[i] : -INFINITY;
+            }
+        }
         float tmax = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            s[i] = key < N ? s[i] : -INFINITY;
-            tmax = fmaxf(tmax, s[i]);
-        }
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);                 // finite: every tile holds at least one real key
         const float alpha = __expf(m_run - m_new);              // exp(-inf) = 0 on the first tile

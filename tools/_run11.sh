@@ -1,0 +1,6 @@
+cd /root/repo
+timeout -k 10 600 python -m pytest tests/test_dav2_gpu.py -x -q > gpurun_out/t_dav2.log 2>&1 || { tail -30 gpurun_out/t_dav2.log; exit 1; }
+tail -2 gpurun_out/t_dav2.log
+timeout -k 10 600 python -c "
+import json, torch, bench
+print(json.dumps(bench.dav2_side(torch.device('cuda:0'), False), indent=1))" > gpurun_out/dav2_side.json 2>gpurun_out/dav2_side.err; cat gpurun_out/dav2_side.json | head -60
