@@ -233,7 +233,8 @@ __global__ __launch_bounds__(NT) void attention_delta_kernel(const float* __rest
 
 __global__ __launch_bounds__(NT, 2) void attention_bwd_dq_kernel(AttnBwdParams p) {
     __shared__ float sO[4][HD][QT + 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q0 = blockIdx.x * QT, head = blockIdx.y, b = blockIdx.z;
     const int N = p.N, C = p.heads * HD;
     const size_t row = (size_t)3 * C;
@@ -255,19 +256,33 @@ __global__ __launch_bounds__(NT, 2) void attention_bwd_dq_kernel(AttnBwdParams p
 #pragma unroll
     for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
     const int ntiles = (N + KT - 1) / KT;
+    // K / V through per-tile buffer resources with loop-invariant lane offsets (see attention_fwd_kernel): key rows past N read zeros
+    const unsigned rowb = (unsigned)row * 4u, kvbytes = (unsigned)((size_t)N * row * 4 - (size_t)(C + head * HD) * 4);
+    unsigned koff[8], ktoff[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) koff[j] = (unsigned)r * rowb + (unsigned)(4 * (2 * j + h)) * 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ktoff[0][j][u] = (unsigned)(8 * j + 4 * h + u) * rowb + (unsigned)r * 4u;
+            ktoff[1][j][u] = ktoff[0][j][u] + 128u;
+        }
     for (int t = wave; t < ntiles; t += 4) {
         const int k0 = t * KT;
-        const int ki = min(k0 + r, N - 1);
+        const unsigned tb = (unsigned)k0 * rowb;
+        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(K)) + tb, 0, (int)(kvbytes - tb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(V)) + tb, 0, (int)(kvbytes - (unsigned)C * 4u - tb), 0x00020000);
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
         {
-            const float* kp = K + (size_t)ki * row;
-            const float* vp = V + (size_t)ki * row;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * (2 * j + h));
-                const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + 4 * (2 * j + h));
+                const f32x4 kk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, koff[j], 0, 0));
+                const f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vr, koff[j], 0, 0));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[u], qv[j][u], s, 0, 0, 0);
@@ -276,20 +291,22 @@ __global__ __launch_bounds__(NT, 2) void attention_bwd_dq_kernel(AttnBwdParams p
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const float pr = key < N ? __expf(s[i] - Lq) : 0.f;
-            s[i] = pr * (dp[i] - Dq);                      // dS^T for (key, my query)
+        for (int i = 0; i < 16; ++i) s[i] = __expf(s[i] - Lq);
+        if (k0 + KT > N) {                                     // (wave-uniform: only the last tile has keys past N)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = k0 + (i & 3) + 8 * (i >> 2) + 4 * h < N ? s[i] : 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] *= dp[i] - Dq;      // dS^T for (key, my query)
         // dQ^T[dim][query] += K^T[dim][key] dS^T[key][query]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int kj = min(k0 + 8 * j + 4 * h + u, N - 1);
-                const float* kp = K + (size_t)kj * row;
-                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[r], s[4 * j + u], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[32 + r], s[4 * j + u], a1, 0, 0, 0);
+                const float ka = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kr, ktoff[0][j][u], 0, 0));
+                const float kb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(kr, ktoff[1][j][u], 0, 0));
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, s[4 * j + u], a0, 0, 0, 0);       // (a key row past N: dS = 0 times K = 0)
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb, s[4 * j + u], a1, 0, 0, 0);
             }
         }
     }
@@ -317,7 +334,8 @@ __global__ __launch_bounds__(NT, 2) void attention_bwd_dq_kernel(AttnBwdParams p
 __global__ __launch_bounds__(NT, 1) void attention_bwd_dkv_kernel(AttnBwdParams p) {
     __shared__ float sK[4][HD][QT + 1];
     __shared__ float sV[4][HD][QT + 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k0 = blockIdx.x * KT, head = blockIdx.y, b = blockIdx.z;
     const int N = p.N, C = p.heads * HD;
     const size_t row = (size_t)3 * C;
@@ -342,19 +360,40 @@ __global__ __launch_bounds__(NT, 1) void attention_bwd_dkv_kernel(AttnBwdParams 
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk0[i] = 0.f; dk1[i] = 0.f; dv0[i] = 0.f; dv1[i] = 0.f; }
     const int ntiles = (N + QT - 1) / QT;
+    // Q / dO rows through per-tile buffer resources with loop-invariant lane offsets (see attention_fwd_kernel): query rows past N
+    // read zeros (their P and dS are masked below)
+    const unsigned rowb = (unsigned)row * 4u, gb = (unsigned)C * 4u;
+    const unsigned qbytes = (unsigned)((size_t)N * row * 4 - (size_t)(head * HD) * 4), gbytes = (unsigned)((size_t)N * C * 4 - (size_t)(head * HD) * 4);
+    unsigned qoff[8], goff[8], qtoff[2][4][4], gtoff[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        qoff[j] = (unsigned)r * rowb + (unsigned)(4 * (2 * j + h)) * 4u;
+        goff[j] = (unsigned)r * gb + (unsigned)(4 * (2 * j + h)) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            qtoff[0][j][u] = (unsigned)(8 * j + 4 * h + u) * rowb + (unsigned)r * 4u;
+            qtoff[1][j][u] = qtoff[0][j][u] + 128u;
+            gtoff[0][j][u] = (unsigned)(8 * j + 4 * h + u) * gb + (unsigned)r * 4u;
+            gtoff[1][j][u] = gtoff[0][j][u] + 128u;
+        }
     for (int t = wave; t < ntiles; t += 4) {
         const int q0 = t * QT;
+        const unsigned tq = (unsigned)q0 * rowb, tg = (unsigned)q0 * gb;
+        const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(Q)) + tq, 0, (int)(qbytes - tq), 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(G)) + tg, 0, (int)(gbytes - tg), 0x00020000);
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
         {
-            const int qi = min(q0 + r, N - 1);
-            const float* qp = Q + (size_t)qi * row;
-            const float* gp = G + (size_t)qi * C;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f32x4 qq = *reinterpret_cast<const f32x4*>(qp + 4 * (2 * j + h)) * p.scale;
-                const f32x4 gg = *reinterpret_cast<const f32x4*>(gp + 4 * (2 * j + h));
+                const f32x4 qq = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qr, qoff[j], 0, 0)) * p.scale;
+                const f32x4 gg = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, goff[j], 0, 0));
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     s = __builtin_amdgcn_mfma_f32_32x32x2f32(qq[u], kv[j][u], s, 0, 0, 0);       // S[query][key]
@@ -363,26 +402,41 @@ __global__ __launch_bounds__(NT, 1) void attention_bwd_dkv_kernel(AttnBwdParams 
             }
         }
         // s[i] / dp[i]: query q0 + (i & 3) + 8 (i >> 2) + 4 h, my key
+        {
+            // log-sum-exp and delta of my 16 queries: per-tile resources again (a query past N reads 0 and is masked in the last tile)
+            const unsigned tl = (unsigned)q0 * 4u;
+            const __amdgpu_buffer_rsrc_t lr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(lse)) + tl, 0, (int)((unsigned)N * 4u - tl), 0x00020000);
+            const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(dlt)) + tl, 0, (int)((unsigned)N * 4u - tl), 0x00020000);
+            float lv[16], dv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            const int qc = min(q, N - 1);
-            const float pr = q < N ? __expf(s[i] - lse[qc]) : 0.f;
-            dp[i] = pr * (dp[i] - dlt[qc]);                 // dS
-            s[i] = pr;                                      // P
+            for (int i = 0; i < 16; ++i) {
+                lv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lr, (unsigned)(16 * h) + (unsigned)(((i & 3) + 8 * (i >> 2)) * 4), 0, 0));
+                dv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, (unsigned)(16 * h) + (unsigned)(((i & 3) + 8 * (i >> 2)) * 4), 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = __expf(s[i] - lv[i]);          // P
+            if (q0 + QT > N) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = q0 + (i & 3) + 8 * (i >> 2) + 4 * h < N ? s[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = s[i] * (dp[i] - dv[i]);       // dS
         }
         // dV^T[dim][key] += dO^T[dim][query] P[query][key];  dK^T[dim][key] += Q^T[dim][query] dS[query][key]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int qj = min(q0 + 8 * j + 4 * h + u, N - 1);
-                const float* gp = G + (size_t)qj * C;
-                const float* qp = Q + (size_t)qj * row;
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[r], s[4 * j + u], dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[32 + r], s[4 * j + u], dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[r], dp[4 * j + u], dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qp[32 + r], dp[4 * j + u], dk1, 0, 0, 0);
+                const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, gtoff[0][j][u], 0, 0));
+                const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, gtoff[1][j][u], 0, 0));
+                const float x0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qr, qtoff[0][j][u], 0, 0));
+                const float x1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qr, qtoff[1][j][u], 0, 0));
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[4 * j + u], dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[4 * j + u], dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, dp[4 * j + u], dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, dp[4 * j + u], dk1, 0, 0, 0);
             }
         }
     }
