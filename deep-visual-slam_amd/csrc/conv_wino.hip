@@ -172,6 +172,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
     static_assert(MT * PP == NT, "one staging item per thread");
     __shared__ __attribute__((aligned(16))) float sV[3][16][MT][CKP];
     __shared__ int sT[MT];
+    __shared__ unsigned sTb[MT];       // byte offset of the tile's first output pixel (channel 0)
     using f32x2 = __attribute__((ext_vector_type(2))) float;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
         sT[tid] = t < ntiles ? (((bb * Ho + 2 * ty) * Wo + 2 * tx) << 3) | (2 * ty + 1 < Ho ? 1 : 0) | (2 * tx + 1 < Wo ? 2 : 0) |
                                    (bb >= p.stat_split ? 4 : 0)
                              : -1;
+        sTb[tid] = (unsigned)((bb * Ho + 2 * ty) * Wo + 2 * tx) * (unsigned)Cout * 4u;
     }
     // ---- my staging item: tile st_tile, channels [VEC st_c, VEC st_c + VEC) of each chunk; byte offsets of its 16 patch pixels
     const int C1 = GEN ? p.C1 : Cin, C2 = Cin - C1;
@@ -423,9 +425,10 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) tinfo[i] = sT[32 * wt + (i & 3) + 8 * (i >> 2) + 4 * h];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tbase[i] = ((unsigned)(tinfo[i] >> 3) * Cout + co) * 4u;
+    for (int i = 0; i < 16; ++i) tbase[i] = sTb[32 * wt + (i & 3) + 8 * (i >> 2) + 4 * h] + (unsigned)co * 4u;
     float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
-    const unsigned row_b = (unsigned)Wo * Cout * 4, col_b = (unsigned)Cout * 4;
+    // (readfirstlane: a store's soffset must be an SGPR; once one of these lands in a vector register every store is a waterfall loop)
+    const unsigned row_b = __builtin_amdgcn_readfirstlane((unsigned)Wo * Cout * 4), col_b = __builtin_amdgcn_readfirstlane((unsigned)Cout * 4);
     float rv[RES ? 16 : 1][4];                            // residual values: all 64 loads in flight before the transform arithmetic
     if constexpr (RES) {
 #pragma unroll
@@ -436,22 +439,76 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
                 rv[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ob, (k >> 1) * row_b + (k & 1) * col_b, 0));
         }
     }
-#pragma unroll
-    for (int ip = 0; ip < 8; ++ip) {
-        const int i = 2 * ip;
-        f32x2 s[2][4], y[2][2];
+    // (a - b on a register pair as ONE v_pk_add_f32 with negated second operand: left to itself the compiler emits two v_sub_f32)
+    auto pk_sub = [](f32x2 a, f32x2 b) __attribute__((always_inline)) {
+        f32x2 d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    };
+    auto out_transform = [&](int i, f32x2 (&y)[2][2]) __attribute__((always_inline)) {
+        f32x2 s[2][4];
 #pragma unroll
         for (int bq = 0; bq < 4; ++bq) {                  // A^T M
             const f32x2 m0{acc[0 + bq][i], acc[0 + bq][i + 1]}, m1{acc[4 + bq][i], acc[4 + bq][i + 1]};
             const f32x2 m2{acc[8 + bq][i], acc[8 + bq][i + 1]}, m3{acc[12 + bq][i], acc[12 + bq][i + 1]};
             s[0][bq] = m0 + m1 + m2;
-            s[1][bq] = m1 - m2 - m3;
+            s[1][bq] = pk_sub(m1, m2 + m3);
         }
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {                  // (A^T M) A
             y[a2][0] = s[a2][0] + s[a2][1] + s[a2][2];
-            y[a2][1] = s[a2][1] - s[a2][2] - s[a2][3];
+            y[a2][1] = pk_sub(s[a2][1], s[a2][2] + s[a2][3]);
         }
+    };
+    // Fast path (wave-uniform): every tile of the wave exists with both rows and columns, one statistics group, no bias / activation
+    // -- the BasicBlock case.  A store is then the tile's offset + one of four SCALAR offsets, no select, no clamp; the statistics
+    // need no masks.  (Every vector instruction here is time no matrix instruction runs in: 1 383 -> ~800 per wave.)
+    bool fast = false;
+    int g0 = 0;
+    if constexpr (!KSPLIT) {
+        g0 = __builtin_amdgcn_readfirstlane(tinfo[0]) & 4;
+        bool mine = co_ok && p.bias == nullptr && !p.relu && (GEN == 0 || p.act == 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine = mine & (tinfo[i] >= 0) & ((tinfo[i] & 7) == (3 | g0));      // (&: no branch chain)
+        fast = __all(mine) != 0;
+    }
+    if (fast) {
+        f32x2 fs{0.f, 0.f}, fq{0.f, 0.f};                  // statistics on register pairs (packed add / fma)
+        auto fast_body = [&](auto with_stats) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ip = 0; ip < 8; ++ip) {
+                const int i = 2 * ip;
+                f32x2 y[2][2];
+                out_transform(i, y);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 yk = y[k >> 1][k & 1];
+                    if constexpr (decltype(with_stats)::value) {
+                        fs += yk;
+                        fq += yk * yk;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float yv = yk[e];
+                        if constexpr (RES) yv += rv[i + e][k];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yr, tbase[i + e], (k >> 1) * row_b + (k & 1) * col_b, 0);
+                    }
+                }
+            }
+        };
+        if (want_stats) fast_body(std::true_type{});
+        else fast_body(std::false_type{});
+        const float f1 = fs[0] + fs[1], q1 = fq[0] + fq[1];
+        ssum[0] = g0 ? 0.f : f1;
+        ssq[0] = g0 ? 0.f : q1;
+        ssum[1] = g0 ? f1 : 0.f;
+        ssq[1] = g0 ? q1 : 0.f;
+    } else
+#pragma unroll
+    for (int ip = 0; ip < 8; ++ip) {
+        const int i = 2 * ip;
+        f32x2 y[2][2];
+        out_transform(i, y);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int info = tinfo[i + e];
