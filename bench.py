@@ -108,6 +108,25 @@ def stock_step(trainer, opt, sample):
     return total_loss, outputs, losses
 
 
+def fresh_process_config(config, steps, warmup):
+    """`python bench.py --config <config>` as a CHILD process (never an exec: this process has initialised the GPU); returns the
+    child's JSON line, or None when it cannot run (under a profiler's preload, or on any failure -- the in-process figure stays)."""
+    import subprocess
+    import sys
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-other-configs", "--no-kernel-timing", "--no-stock-caller"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
+
+
 def time_stock(batch, num_scales, device, rank, steps, warmup):
     trainer, opt, sample = build_stock(batch, num_scales, device, rank)
     for _ in range(warmup):
@@ -653,7 +672,8 @@ def main():
             out["other_configs"] = {"configs[1]": {"workload": c2["name"], "value": 3.0 * c2["batch"] * args.steps / dt2,
                                                    "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
                                                    "per_gpu_batch": c2["batch"], "num_scales": c2["num_scales"],
-                                                   "loss_check": check2}}
+                                                   "loss_check": check2,
+                                                   "process": "this process, after the configs[2] trainer and the stock caller"}}
             del tr2, sync2, opt2, sample2
             torch.cuda.synchronize()
             gradsink.reset_streams()
@@ -666,6 +686,16 @@ def main():
             gradsink.reset_streams()
             gc.collect()
             torch.cuda.empty_cache()
+            # configs[1] is host-bound, and a process that has already built (and dropped) two trainers issues it ~2 ms per step
+            # slower than a fresh one (HIP hands later streams hardware queues that earlier, destroyed streams still map to):
+            # what a user who trains configs[1] gets is the fresh-process figure, so it is measured that way too -- the same
+            # file, `--config c2`, as a child process while this one idles -- and both figures are reported.
+            fresh = fresh_process_config("c2", args.steps, args.warmup)
+            if fresh is not None:
+                c1 = out["other_configs"]["configs[1]"]
+                c1["in_process"] = {"value": c1["value"], "ms_per_step": c1["ms_per_step"], "process": c1["process"]}
+                c1.update(value=fresh["value"], ms_per_step=fresh["ms_per_step"], median_ms_per_step=fresh.get("median_ms_per_step"),
+                          loss_check=fresh.get("loss_check"), process="fresh child process: python bench.py --config c2")
             out["other_configs"]["configs[0]"] = inference_side(device, not args.no_cpu_baseline)
             out["other_configs"]["configs[4]"] = dav2_side(device, not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)

@@ -6,6 +6,7 @@ that both share one HIP runtime (libamdhip64.so.7) and therefore one set of stre
 """
 import ctypes as C
 import os
+import threading
 
 import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstring)
 
@@ -216,10 +217,36 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_stream_tls = threading.local()
+
+
+class on_stream:
+    """`with _lib.on_stream(side):` -- the dvs_* calls inside are handed `side` instead of torch's current stream, WITHOUT
+    switching torch's current stream (torch.cuda.stream() costs ~15 us per enter / exit pair, and the weight-gradient branch of every
+    convolution's backward takes one).  Only for code that allocates nothing inside: torch's allocator would hand out memory
+    that belongs to the current stream."""
+    __slots__ = ("handle", "prev")
+
+    def __init__(self, torch_stream):
+        self.handle = torch_stream.cuda_stream
+
+    def __enter__(self):
+        self.prev = getattr(_stream_tls, "override", None)
+        _stream_tls.override = self.handle
+        return self
+
+    def __exit__(self, *exc):
+        _stream_tls.override = self.prev
+        return False
+
+
 def stream():
-    """hipStream_t of torch's current stream on the current device (what every dvs_* call is handed).  Uses torch's raw
-    accessor when it exists: `torch.cuda.current_stream()` builds a Stream object (~10 us), and this is called once per
-    kernel launch -- 2.5 ms of host time per training step."""
+    """hipStream_t of torch's current stream on the current device (what every dvs_* call is handed), or the stream of an
+    enclosing `on_stream`.  Uses torch's raw accessor when it exists: `torch.cuda.current_stream()` builds a Stream object
+    (~10 us), and this is called once per kernel launch -- 2.5 ms of host time per training step."""
+    o = getattr(_stream_tls, "override", None)
+    if o is not None:
+        return o
     if _raw_stream is not None and _get_device is not None:
         return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream

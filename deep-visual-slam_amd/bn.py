@@ -101,7 +101,7 @@ class _BNAct(torch.autograd.Function):
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
         for par in ctx.affine:
-            gradsink.note(par, torch.cuda.current_stream())
+            gradsink.note(par, gradsink.cur_stream())
         ds_res = residual is not None and res_fin is not None
         d_res = None
         if residual is not None:
@@ -192,7 +192,7 @@ class _BNReluPool(torch.autograd.Function):
         gs, bs = gradsink.target(g_par), gradsink.target(b_par)
         sunk = gs is not None and bs is not None
         for par in ctx.affine:
-            gradsink.note(par, torch.cuda.current_stream())
+            gradsink.note(par, gradsink.cur_stream())
         check(l.dvs_bn_relu_maxpool_bwd(dpool.data_ptr(), idx.data_ptr(), dz.data_ptr() if dz is not None else None, y.data_ptr(), fin.data_ptr(), ptr(gamma),
                                         sums.data_ptr(), ptr(ws), dy.data_ptr(), B, H, W, C, ptr(gs) if sunk else None,
                                         ptr(bs) if sunk else None, G, _lib.stream()), "dvs_bn_relu_maxpool_bwd")

@@ -588,7 +588,7 @@ class _Conv2d(torch.autograd.Function):
             if ctx.has_bias and ctx.needs_input_grad[2] and 256 % (Cout // 4) == 0:
                 bs = gradsink.target(ctx.bias_ref)
                 if bs is not None:
-                    gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
+                    gradsink.note(ctx.bias_ref, gradsink.cur_stream())
                     db_ptr, pre_db = bs.data_ptr(), True
                 else:
                     pre_db = zeropool.zeros((Cout,), dy.device, pooled=_has_grad(ctx.bias_ref))
@@ -641,8 +641,8 @@ class _Conv2d(torch.autograd.Function):
                         and wino_dec_wgrad_pays(dy.shape[0], dy.shape[2], dy.shape[3], weight.shape[1], weight.shape[0]))
             if side is None:
                 if wsink is not None or bsink is not None:
-                    gradsink.note(weight, torch.cuda.current_stream())
-                    gradsink.note(ctx.bias_ref, torch.cuda.current_stream())
+                    gradsink.note(weight, gradsink.cur_stream())
+                    gradsink.note(ctx.bias_ref, gradsink.cur_stream())
                 if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 elif wino_gen:
@@ -655,11 +655,16 @@ class _Conv2d(torch.autograd.Function):
                 if pre_db is not None and pre_db is not True:
                     db = pre_db
             else:
-                cur = torch.cuda.current_stream()
+                cur = gradsink.cur_stream()
+                # layout copies (if any) run HERE, on the compute stream, in front of the side stream's wait
+                x, dy = _nhwc(x), _nhwc(dy)
+                y = _nhwc(y) if isinstance(y, torch.Tensor) else y
+                x2 = _nhwc(x2) if isinstance(x2, torch.Tensor) else x2
                 gradsink.note(weight, cur, side)
                 gradsink.note(ctx.bias_ref, cur, side)
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
+                # (the ordered / deterministic forms allocate a workspace inside: those need torch's current stream switched)
+                with (torch.cuda.stream(side) if (_WGRAD_ORDERED or _lib.deterministic()) else _lib.on_stream(side)):
                     if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
                     elif wino_gen:
@@ -715,8 +720,8 @@ class _HeadConv(torch.autograd.Function):
         wsink, bsink = gradsink.target(ctx.params[0]), gradsink.target(ctx.params[1])
         if wsink is not None and not wsink.permute(0, 2, 3, 1).is_contiguous():
             wsink = None
-        gradsink.note(ctx.params[0], torch.cuda.current_stream())
-        gradsink.note(ctx.params[1], torch.cuda.current_stream())
+        gradsink.note(ctx.params[0], gradsink.cur_stream())
+        gradsink.note(ctx.params[1], gradsink.cur_stream())
         dw = wsink if wsink is not None else zeropool.zeros(tuple(w.shape), x.device, channels_last=True, pooled=ctx.pooled)
         db = bsink if bsink is not None else (zeropool.zeros((w.shape[0],), x.device, pooled=ctx.pooled) if has_bias else None)
         res = None

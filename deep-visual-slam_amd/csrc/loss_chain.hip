@@ -33,6 +33,12 @@ constexpr float K9 = 1.0f / 9.0f;
 #ifndef FWD_WAVES
 #define FWD_WAVES 3   // waves per SIMD the register allocator targets (4 and 3 spill: checked with -Rpass-analysis)
 #endif
+#ifndef FWD_STAGE_NB
+#define FWD_STAGE_NB 2  // the same for chain_fwd_kernel (168 registers at three waves per SIMD)
+#endif
+#ifndef STAGE_NB
+#define STAGE_NB 3      // pixels per thread and staging batch (see chain_bwd_kernel)
+#endif
 #ifndef BWD_WAVES
 #define BWD_WAVES 2
 #endif
@@ -480,42 +486,67 @@ __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p)
             float* o_dup = (f == 0) ? p.io.disp_up[s] : nullptr;
             float* o_depth = (f == 0) ? p.io.depth[s] : nullptr;
             const bool materialize = o_color || o_grid || o_dup || o_depth;
-            for (int i = tid; i < PL; i += NT) {
-                const uint32_t h = sH[i];
-                const int gx = (int)(h & 0xffffu), gy = (int)((h >> 16) & 0x7fffu);
-                // the upsampled disparity is formed for frame -1 and re-read from the LDS tile for frame +1
-                float du;
-                if (f == 0) {
-                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
-                    sD[i] = du;
-                } else {
-                    du = sD[i];
+            // batches of FWD_STAGE_NB pixels per thread: a batch's disparity taps, then all its gathers, are in flight together
+            // (one or two memory round trips per batch instead of per pixel)
+            for (int base = 0; base < PL; base += FWD_STAGE_NB * NT) {
+                int idx[FWD_STAGE_NB];
+                uint32_t hh[FWD_STAGE_NB];
+                float du[FWD_STAGE_NB], dep[FWD_STAGE_NB], wgx[FWD_STAGE_NB], wgy[FWD_STAGE_NB], wtx[FWD_STAGE_NB], wty[FWD_STAGE_NB];
+                f4 nw[FWD_STAGE_NB], ne[FWD_STAGE_NB], sw[FWD_STAGE_NB], se[FWD_STAGE_NB];
+#pragma unroll
+                for (int u = 0; u < FWD_STAGE_NB; ++u) {
+                    if (base + u * NT >= PL) continue;                         // (workgroup-uniform)
+                    const int i = base + u * NT + tid;
+                    idx[u] = i < PL ? i : -1;
+                    hh[u] = sH[min(i, PL - 1)];                                // past the end: the last pixel again, not stored
+                    const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
+                    // the upsampled disparity is formed for frame -1 and re-read from the LDS tile for frame +1
+                    du[u] = (f == 0) ? disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx) : sD[min(i, PL - 1)];
                 }
-                const float depth = frcp(geo.min_disp + geo.disp_range * du);
-                float c0, c1, c2;
-                pixel_ray(cam, gx, gy, c0, c1, c2);
-                Warp w;
-                warp_project(P, geo, depth, c0, c1, c2, w);
-                f4 nw, ne, sw, se;
-                gather_rgba(src4, W, w, nw, ne, sw, se);
-                const f4 c4 = bilerp4(w, nw, ne, sw, se);
-                const float col[3] = {c4[0], c4[1], c4[2]};
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) sXf[ch * PL + i] = col[ch];
-                // optional materialisation of the reference's `outputs` tensors (interior pixels only)
-                if (materialize && (h >> 31)) {
-                    const size_t o = (size_t)b * HW + (size_t)gy * W + gx;        // interior: (gx, gy) is the pixel itself
-                    if (o_color) {
+                for (int u = 0; u < FWD_STAGE_NB; ++u) {
+                    if (base + u * NT >= PL) continue;
+                    const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
+                    dep[u] = frcp(geo.min_disp + geo.disp_range * du[u]);
+                    float c0, c1, c2;
+                    pixel_ray(cam, gx, gy, c0, c1, c2);
+                    Warp w;
+                    warp_project(P, geo, dep[u], c0, c1, c2, w);
+                    gather_rgba(src4, W, w, nw[u], ne[u], sw[u], se[u]);
+                    wgx[u] = w.gx;
+                    wgy[u] = w.gy;
+                    wtx[u] = w.tx;
+                    wty[u] = w.ty;
+                }
 #pragma unroll
-                        for (int ch = 0; ch < 3; ++ch)
-                            o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)gy * W + gx] = col[ch];
+                for (int u = 0; u < FWD_STAGE_NB; ++u) {
+                    if (base + u * NT >= PL) continue;
+                    Warp w;
+                    w.tx = wtx[u];
+                    w.ty = wty[u];
+                    const f4 c4 = bilerp4(w, nw[u], ne[u], sw[u], se[u]);
+                    const float col[3] = {c4[0], c4[1], c4[2]};
+                    if (idx[u] < 0) continue;
+                    const int i = idx[u];
+                    if (f == 0) sD[i] = du[u];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) sXf[ch * PL + i] = col[ch];
+                    // optional materialisation of the reference's `outputs` tensors (interior pixels only)
+                    if (materialize && (hh[u] >> 31)) {
+                        const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
+                        const size_t o = (size_t)b * HW + (size_t)gy * W + gx;        // interior: (gx, gy) is the pixel itself
+                        if (o_color) {
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch)
+                                o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)gy * W + gx] = col[ch];
+                        }
+                        if (o_grid) {
+                            o_grid[o * 2 + 0] = wgx[u];
+                            o_grid[o * 2 + 1] = wgy[u];
+                        }
+                        if (o_dup) o_dup[o] = du[u];
+                        if (o_depth) o_depth[o] = dep[u];
                     }
-                    if (o_grid) {
-                        o_grid[o * 2 + 0] = w.gx;
-                        o_grid[o * 2 + 1] = w.gy;
-                    }
-                    if (o_dup) o_dup[o] = du;
-                    if (o_depth) o_depth[o] = depth;
                 }
             }
         }
@@ -705,25 +736,48 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
             const float* P = cam + 12 + 12 * f;
             const f4* src4 = packed_source(p, f, b);
             const uint32_t want = 2u + (uint32_t)f;
-            for (int i = tid; i < PLB; i += NT) {
-                const uint32_t h = sH[i];
-                const int gx = (int)(h & 0xffffu), gy = (int)(h >> 16);
-                float du;
-                if (f == 0) {
-                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
-                    sD[i] = du;
-                } else {
-                    du = sD[i];
-                }
-                float c0, c1, c2;
-                pixel_ray(cam, gx, gy, c0, c1, c2);
-                Warp w;
-                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);
-                f4 nw, ne, sw, se;
-                gather_rgba(src4, W, w, nw, ne, sw, se);
-                const f4 c4 = bilerp4(w, nw, ne, sw, se);
+            // Staging in batches of STAGE_NB pixels per thread: the disparity taps of the whole batch, then all its gathers, are in
+            // flight together -- one memory round trip (two for frame 0) per batch instead of one per pixel, which at two waves
+            // per SIMD was most of this phase (6 dependent round trips per scale and frame).
+            for (int base = 0; base < PLB; base += STAGE_NB * NT) {
+                int idx[STAGE_NB], pgx[STAGE_NB], pgy[STAGE_NB];
+                float du[STAGE_NB];
+                f4 nw[STAGE_NB], ne[STAGE_NB], sw[STAGE_NB], se[STAGE_NB];
+                float wtx[STAGE_NB], wty[STAGE_NB];
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) sX[ch * PLB + i] = c4[ch];
+                for (int u = 0; u < STAGE_NB; ++u) {
+                    if (base + u * NT >= PLB) continue;                       // (workgroup-uniform)
+                    const int i = base + u * NT + tid;
+                    idx[u] = i < PLB ? i : -1;
+                    const uint32_t h = sH[min(i, PLB - 1)];                   // past the end: the last pixel again, not stored
+                    pgx[u] = (int)(h & 0xffffu);
+                    pgy[u] = (int)(h >> 16);
+                    du[u] = (f == 0) ? disp_up_at(dsp, hs, ws, same_res, W, pgx[u], pgy[u], ry, rx) : sD[min(i, PLB - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < STAGE_NB; ++u) {
+                    if (base + u * NT >= PLB) continue;
+                    float c0, c1, c2;
+                    pixel_ray(cam, pgx[u], pgy[u], c0, c1, c2);
+                    Warp w;
+                    warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du[u]), c0, c1, c2, w);
+                    gather_rgba(src4, W, w, nw[u], ne[u], sw[u], se[u]);
+                    wtx[u] = w.tx;
+                    wty[u] = w.ty;
+                }
+#pragma unroll
+                for (int u = 0; u < STAGE_NB; ++u) {
+                    if (base + u * NT >= PLB) continue;
+                    Warp w;
+                    w.tx = wtx[u];
+                    w.ty = wty[u];
+                    const f4 c4 = bilerp4(w, nw[u], ne[u], sw[u], se[u]);
+                    if (idx[u] >= 0) {
+                        if (f == 0) sD[idx[u]] = du[u];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) sX[ch * PLB + idx[u]] = c4[ch];
+                    }
+                }
             }
             __syncthreads();
 
