@@ -85,4 +85,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// 64-lane sum on the DPP path of the vector ALU (no LDS crossbar, no lgkmcnt wait): quad swaps, the two row mirrors, then the
+// row broadcasts that gfx9 / CDNA have.  Only LANE 63 ends with the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v = dpp_add<0xB1, 0xF>(v);      // quad_perm [1, 0, 3, 2]
+    v = dpp_add<0x4E, 0xF>(v);      // quad_perm [2, 3, 0, 1]
+    v = dpp_add<0x141, 0xF>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);     // row_mirror: every lane of a 16-lane row holds the row's sum
+    v = dpp_add<0x142, 0xA>(v);     // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);     // row_bcast31 into rows 2 and 3
+    return v;
+}
+
 }  // namespace dvs

@@ -33,15 +33,15 @@ constexpr float K9 = 1.0f / 9.0f;
 #ifndef FWD_WAVES
 #define FWD_WAVES 3   // waves per SIMD the register allocator targets (4 and 3 spill: checked with -Rpass-analysis)
 #endif
-#ifndef FWD_STAGE_NB
-#define FWD_STAGE_NB 2  // the same for chain_fwd_kernel (168 registers at three waves per SIMD)
-#endif
-#ifndef STAGE_NB
-#define STAGE_NB 3      // pixels per thread and staging batch (see chain_bwd_kernel)
-#endif
 #ifndef BWD_WAVES
 #define BWD_WAVES 2
 #endif
+#ifndef CHAIN_DBG
+#define CHAIN_DBG 0   // timing cuts of chain_bwd_kernel (tools/chain_cuts.sh): 1 no gathers in staging, 2 no field phase, 4 no 3x3 gather,
+#endif                // 8 no chain phase, 16 no wave reductions -- results are wrong with any bit set
+#ifndef BWD_NT
+#define BWD_NT 256    // threads per workgroup of chain_bwd_kernel: 256 (4 rows per lane, the default) or 512 (2 rows per lane, four waves per SIMD:
+#endif                // measured equal before the owner-thread staging, slower after it -- 128 registers spill)
 constexpr int FIELD_ROWS = 6, FIELD_THREADS = FW * (FH / FIELD_ROWS);  // 66 columns x 3 row groups
 static_assert(FH % FIELD_ROWS == 0 && FIELD_THREADS <= NT, "field strips must tile the 1-px-halo tile");
 static_assert(ACC_H * ACC_W <= 3 * FH * FW, "sAcc aliases sF");
@@ -486,67 +486,42 @@ __global__ __launch_bounds__(NT, FWD_WAVES) void chain_fwd_kernel(ChainParams p)
             float* o_dup = (f == 0) ? p.io.disp_up[s] : nullptr;
             float* o_depth = (f == 0) ? p.io.depth[s] : nullptr;
             const bool materialize = o_color || o_grid || o_dup || o_depth;
-            // batches of FWD_STAGE_NB pixels per thread: a batch's disparity taps, then all its gathers, are in flight together
-            // (one or two memory round trips per batch instead of per pixel)
-            for (int base = 0; base < PL; base += FWD_STAGE_NB * NT) {
-                int idx[FWD_STAGE_NB];
-                uint32_t hh[FWD_STAGE_NB];
-                float du[FWD_STAGE_NB], dep[FWD_STAGE_NB], wgx[FWD_STAGE_NB], wgy[FWD_STAGE_NB], wtx[FWD_STAGE_NB], wty[FWD_STAGE_NB];
-                f4 nw[FWD_STAGE_NB], ne[FWD_STAGE_NB], sw[FWD_STAGE_NB], se[FWD_STAGE_NB];
-#pragma unroll
-                for (int u = 0; u < FWD_STAGE_NB; ++u) {
-                    if (base + u * NT >= PL) continue;                         // (workgroup-uniform)
-                    const int i = base + u * NT + tid;
-                    idx[u] = i < PL ? i : -1;
-                    hh[u] = sH[min(i, PL - 1)];                                // past the end: the last pixel again, not stored
-                    const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
-                    // the upsampled disparity is formed for frame -1 and re-read from the LDS tile for frame +1
-                    du[u] = (f == 0) ? disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx) : sD[min(i, PL - 1)];
+            for (int i = tid; i < PL; i += NT) {
+                const uint32_t h = sH[i];
+                const int gx = (int)(h & 0xffffu), gy = (int)((h >> 16) & 0x7fffu);
+                // the upsampled disparity is formed for frame -1 and re-read from the LDS tile for frame +1
+                float du;
+                if (f == 0) {
+                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
+                    sD[i] = du;
+                } else {
+                    du = sD[i];
                 }
+                const float depth = frcp(geo.min_disp + geo.disp_range * du);
+                float c0, c1, c2;
+                pixel_ray(cam, gx, gy, c0, c1, c2);
+                Warp w;
+                warp_project(P, geo, depth, c0, c1, c2, w);
+                f4 nw, ne, sw, se;
+                gather_rgba(src4, W, w, nw, ne, sw, se);
+                const f4 c4 = bilerp4(w, nw, ne, sw, se);
+                const float col[3] = {c4[0], c4[1], c4[2]};
 #pragma unroll
-                for (int u = 0; u < FWD_STAGE_NB; ++u) {
-                    if (base + u * NT >= PL) continue;
-                    const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
-                    dep[u] = frcp(geo.min_disp + geo.disp_range * du[u]);
-                    float c0, c1, c2;
-                    pixel_ray(cam, gx, gy, c0, c1, c2);
-                    Warp w;
-                    warp_project(P, geo, dep[u], c0, c1, c2, w);
-                    gather_rgba(src4, W, w, nw[u], ne[u], sw[u], se[u]);
-                    wgx[u] = w.gx;
-                    wgy[u] = w.gy;
-                    wtx[u] = w.tx;
-                    wty[u] = w.ty;
-                }
+                for (int ch = 0; ch < 3; ++ch) sXf[ch * PL + i] = col[ch];
+                // optional materialisation of the reference's `outputs` tensors (interior pixels only)
+                if (materialize && (h >> 31)) {
+                    const size_t o = (size_t)b * HW + (size_t)gy * W + gx;        // interior: (gx, gy) is the pixel itself
+                    if (o_color) {
 #pragma unroll
-                for (int u = 0; u < FWD_STAGE_NB; ++u) {
-                    if (base + u * NT >= PL) continue;
-                    Warp w;
-                    w.tx = wtx[u];
-                    w.ty = wty[u];
-                    const f4 c4 = bilerp4(w, nw[u], ne[u], sw[u], se[u]);
-                    const float col[3] = {c4[0], c4[1], c4[2]};
-                    if (idx[u] < 0) continue;
-                    const int i = idx[u];
-                    if (f == 0) sD[i] = du[u];
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) sXf[ch * PL + i] = col[ch];
-                    // optional materialisation of the reference's `outputs` tensors (interior pixels only)
-                    if (materialize && (hh[u] >> 31)) {
-                        const int gx = (int)(hh[u] & 0xffffu), gy = (int)((hh[u] >> 16) & 0x7fffu);
-                        const size_t o = (size_t)b * HW + (size_t)gy * W + gx;        // interior: (gx, gy) is the pixel itself
-                        if (o_color) {
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch)
-                                o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)gy * W + gx] = col[ch];
-                        }
-                        if (o_grid) {
-                            o_grid[o * 2 + 0] = wgx[u];
-                            o_grid[o * 2 + 1] = wgy[u];
-                        }
-                        if (o_dup) o_dup[o] = du[u];
-                        if (o_depth) o_depth[o] = dep[u];
+                        for (int ch = 0; ch < 3; ++ch)
+                            o_color[(size_t)b * 3 * HW + (size_t)ch * HW + (size_t)gy * W + gx] = col[ch];
                     }
+                    if (o_grid) {
+                        o_grid[o * 2 + 0] = w.gx;
+                        o_grid[o * 2 + 1] = w.gy;
+                    }
+                    if (o_dup) o_dup[o] = du;
+                    if (o_depth) o_depth[o] = depth;
                 }
             }
         }
@@ -668,14 +643,22 @@ struct BwdParams {
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p, BwdParams q) {
+// NTB threads own PXB rows of a column each (NTB / 64 waves x PXB = the TH rows of the tile): 256 x 4 at two waves per SIMD, or
+// 512 x 2 at four -- same tile and LDS, half the per-thread state, twice the waves to hide LDS / gather latency and barriers behind.
+template <int NTB, int PXB>
+__global__ __launch_bounds__(NTB, NTB == 512 ? 4 : BWD_WAVES) void chain_bwd_kernel(ChainParams p, BwdParams q) {
+    static_assert((NTB / 64) * PXB == TH, "waves x rows per lane = tile height");
+    constexpr int NWV = NTB / 64;
+    constexpr int RING = BH * BW - TH * TW;                                      // pixels of the 2-px halo ring
+    constexpr int FR = NTB == 512 ? 3 : FIELD_ROWS, FT = FW * (FH / FR);      // field strips: 66 columns x (18 / FR) row groups
+    static_assert(FH % FR == 0 && FT <= NTB, "field strips must tile the 1-px-halo tile");
     __shared__ float sT[3 * BH * BW];
     __shared__ float sX[3 * BH * BW];
     __shared__ float sD[BH * BW];
     __shared__ float sF[3 * FH * FW];     // SSIM derivative fields of one channel; reused as sAcc
     __shared__ uint8_t sSel[FH * FW];
     __shared__ uint32_t sH[BH * BW];      // halo positions gx | gy << 16 of the 2-px-halo tile (see the forward kernel)
-    __shared__ float sRed[NT / 64][NDP];
+    __shared__ float sRed[NTB / 64][NDP];
     float* sAcc = sF;
 
     const dvs_chain_cfg& c = p.cfg;
@@ -686,10 +669,10 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
     const Geo geo = make_geo(c);
     constexpr int PLB = BH * BW, PLF = FH * FW;
     const int tile = blockIdx.y * p.tiles_x + blockIdx.x, ntiles = p.tiles_x * p.tiles_y;
-    const int X = X0 + tx, Yb = Y0 + PX * ty;      // my strip: column X, rows Yb .. Yb+3
+    const int X = X0 + tx, Yb = Y0 + PXB * ty;      // my strip: column X, rows Yb .. Yb+3
 
     const float* tgt = p.io.target + (size_t)b * 3 * HW;
-    for (int i = tid; i < PLB; i += NT) {
+    for (int i = tid; i < PLB; i += NTB) {
         int hy = i / BW, hx = i - hy * BW;
         int gx = reflect_idx(X0 - 2 + hx, W), gy = reflect_idx(Y0 - 2 + hy, H);
         sH[i] = (uint32_t)gx | ((uint32_t)gy << 16);
@@ -697,7 +680,7 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
         for (int ch = 0; ch < 3; ++ch) sT[ch * PLB + i] = tgt[ch * HW + gy * W + gx];
     }
     const float* cam = cam_table(p, b);        // uniform: scalar loads (written by the forward call)
-    for (int i = tid; i < PLF; i += NT) {
+    for (int i = tid; i < PLF; i += NTB) {
         int hy = i / FW, hx = i - hy * FW;
         int px = X0 - 1 + hx, py = Y0 - 1 + hy;
         bool in = px >= 0 && px < W && py >= 0 && py < H;
@@ -714,8 +697,8 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
     const float wxm = (X == 1) ? 2.f : 1.f, wxp = (X == W - 2) ? 2.f : 1.f;
 
     // field strip owned by this thread: column fcol, rows frow0 .. frow0+5 of the 1-px-halo tile
-    const int fcol = tid % FW, frow0 = (tid / FW) * FIELD_ROWS;
-    const bool field_thread = tid < FIELD_THREADS;
+    const int fcol = tid % FW, frow0 = (tid / FW) * FR;
+    const bool field_thread = tid < FT;
     const int fpx = X0 - 1 + fcol;
 
     const int s_lo = (q.g.scale_end > q.g.scale_begin) ? q.g.scale_begin : 0;
@@ -729,69 +712,77 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
         const float gl = q.g.d_losses[s];
         const float w_ssim = gl * w_pix * c.ssim_ratio * (1.f / 3.f) * (-0.5f) * K9;
         const float w_l1 = gl * w_pix * (1.f - c.ssim_ratio) * (1.f / 3.f);
-        float gd[PX] = {0.f, 0.f, 0.f, 0.f};  // d loss / d disp_up at my pixels
+        float gd[PXB];                        // d loss / d disp_up at my pixels
+#pragma unroll
+        for (int k = 0; k < PXB; ++k) gd[k] = 0.f;
 
 #pragma unroll 1
         for (int f = 0; f < 2; ++f) {
             const float* P = cam + 12 + 12 * f;
             const f4* src4 = packed_source(p, f, b);
             const uint32_t want = 2u + (uint32_t)f;
-            // Staging in batches of STAGE_NB pixels per thread: the disparity taps of the whole batch, then all its gathers, are in
-            // flight together -- one memory round trip (two for frame 0) per batch instead of one per pixel, which at two waves
-            // per SIMD was most of this phase (6 dependent round trips per scale and frame).
-            for (int base = 0; base < PLB; base += STAGE_NB * NT) {
-                int idx[STAGE_NB], pgx[STAGE_NB], pgy[STAGE_NB];
-                float du[STAGE_NB];
-                f4 nw[STAGE_NB], ne[STAGE_NB], sw[STAGE_NB], se[STAGE_NB];
-                float wtx[STAGE_NB], wty[STAGE_NB];
-#pragma unroll
-                for (int u = 0; u < STAGE_NB; ++u) {
-                    if (base + u * NT >= PLB) continue;                       // (workgroup-uniform)
-                    const int i = base + u * NT + tid;
-                    idx[u] = i < PLB ? i : -1;
-                    const uint32_t h = sH[min(i, PLB - 1)];                   // past the end: the last pixel again, not stored
-                    pgx[u] = (int)(h & 0xffffu);
-                    pgy[u] = (int)(h >> 16);
-                    du[u] = (f == 0) ? disp_up_at(dsp, hs, ws, same_res, W, pgx[u], pgy[u], ry, rx) : sD[min(i, PLB - 1)];
+            // Staging: warp every pixel of the tile + 2-px halo into sX.  A thread stages ITS OWN pixels first and keeps the x / y
+            // differences of their four taps (times the coordinate masks and the projective 1 / z) in registers -- the chain phase
+            // below then needs neither the projection's gather nor the taps again (it was a fifth of the kernel: four dependent
+            // gathers per pixel at the end of every frame) -- and the 336 pixels of the halo ring are spread over the threads.
+            auto stage = [&](int i, float (*keep)[2]) __attribute__((always_inline)) {
+                const uint32_t h = sH[i];
+                const int gx = (int)(h & 0xffffu), gy = (int)(h >> 16);
+                float du;
+                if (f == 0) {
+                    du = disp_up_at(dsp, hs, ws, same_res, W, gx, gy, ry, rx);
+                    sD[i] = du;
+                } else {
+                    du = sD[i];
                 }
+                float c0, c1, c2;
+                pixel_ray(cam, gx, gy, c0, c1, c2);
+                Warp w;
+                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);
+                f4 nw, ne, sw, se;
+                if (CHAIN_DBG & 1) nw = ne = sw = se = f4{w.u, w.v, w.gx, w.gy};
+                else gather_rgba(src4, W, w, nw, ne, sw, se);
+                const f4 c4 = bilerp4(w, nw, ne, sw, se);
 #pragma unroll
-                for (int u = 0; u < STAGE_NB; ++u) {
-                    if (base + u * NT >= PLB) continue;
-                    float c0, c1, c2;
-                    pixel_ray(cam, pgx[u], pgy[u], c0, c1, c2);
-                    Warp w;
-                    warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du[u]), c0, c1, c2, w);
-                    gather_rgba(src4, W, w, nw[u], ne[u], sw[u], se[u]);
-                    wtx[u] = w.tx;
-                    wty[u] = w.ty;
-                }
+                for (int ch = 0; ch < 3; ++ch) sX[ch * PLB + i] = c4[ch];
+                if (keep) {
+                    // d colour / d ix, d colour / d iy (grid_sample's bilinear derivative) times d ix / d u = mask, and 1 / z
+                    const f4 ddx = ((ne - nw) * (1.f - w.ty) + (se - sw) * w.ty) * (w.mx * w.rden);
+                    const f4 ddy = ((sw - nw) * (1.f - w.tx) + (se - ne) * w.tx) * (w.my * w.rden);
 #pragma unroll
-                for (int u = 0; u < STAGE_NB; ++u) {
-                    if (base + u * NT >= PLB) continue;
-                    Warp w;
-                    w.tx = wtx[u];
-                    w.ty = wty[u];
-                    const f4 c4 = bilerp4(w, nw[u], ne[u], sw[u], se[u]);
-                    if (idx[u] >= 0) {
-                        if (f == 0) sD[idx[u]] = du[u];
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) sX[ch * PLB + idx[u]] = c4[ch];
+                    for (int ch = 0; ch < 3; ++ch) {
+                        keep[ch][0] = ddx[ch];
+                        keep[ch][1] = ddy[ch];
                     }
                 }
+            };
+            float tapd[PXB][3][2];
+#pragma unroll
+            for (int k = 0; k < PXB; ++k) stage((PXB * ty + k + 2) * BW + tx + 2, tapd[k]);
+            for (int j = tid; j < RING; j += NTB) {
+                // ring pixel j -> tile index: rows 0, 1, then rows BH-2, BH-1, then columns 0, 1, BW-2, BW-1 of the rows between
+                int i;
+                if (j < 2 * BW) i = j;
+                else if (j < 4 * BW) i = (BH - 4) * BW + j;                    // (BH - 2) * BW + (j - 2 * BW)
+                else {
+                    const int r = j - 4 * BW, c = r & 3;
+                    i = (2 + (r >> 2)) * BW + (c < 2 ? c : BW - 4 + c);
+                }
+                stage(i, nullptr);
             }
             __syncthreads();
 
-            float dcol[PX][3];
+            float dcol[PXB][3];
 #pragma unroll 1
             for (int ch = 0; ch < 3; ++ch) {
                 // SSIM derivative coefficient fields at every pixel p of tile + 1-px halo:
                 // d out / d x(r) = -1/2 * 1/9 * (alpha(p) + beta(p) x(r) + gamma(p) y(r)) for r in window(p)
-                if (field_thread) {
+                if (field_thread && !(CHAIN_DBG & 2)) {
                     const float* xw = sX + ch * PLB + frow0 * BW + fcol;
                     const float* yw = sT + ch * PLB + frow0 * BW + fcol;
                     RowSums r0 = row_sums(xw, yw), r1 = row_sums(xw + BW, yw + BW);
 #pragma unroll
-                    for (int j = 0; j < FIELD_ROWS; ++j) {
+                    for (int j = 0; j < FR; ++j) {
                         RowSums r2 = row_sums(xw + (j + 2) * BW, yw + (j + 2) * BW);
                         int hy = frow0 + j, i = hy * FW + fcol, py = Y0 - 1 + hy;
                         float fa = 0.f, fb = 0.f, fc = 0.f;
@@ -819,27 +810,30 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
                     }
                 }
                 __syncthreads();
-                {
-                    // separable 3x3 gather of the three fields for my 4-row strip (rows PX*ty .. +5 of sF)
-                    float ha[PX + 2], hb[PX + 2], hc[PX + 2];
+                if (CHAIN_DBG & 4) {
 #pragma unroll
-                    for (int j = 0; j < PX + 2; ++j) {
-                        int o = (PX * ty + j) * FW + tx;
+                    for (int k = 0; k < PXB; ++k) dcol[k][ch] = sX[ch * PLB + (PXB * ty + k + 2) * BW + tx + 2];
+                } else {
+                    // separable 3x3 gather of the three fields for my 4-row strip (rows PXB*ty .. +5 of sF)
+                    float ha[PXB + 2], hb[PXB + 2], hc[PXB + 2];
+#pragma unroll
+                    for (int j = 0; j < PXB + 2; ++j) {
+                        int o = (PXB * ty + j) * FW + tx;
                         ha[j] = wxm * sF[o] + sF[o + 1] + wxp * sF[o + 2];
                         hb[j] = wxm * sF[PLF + o] + sF[PLF + o + 1] + wxp * sF[PLF + o + 2];
                         hc[j] = wxm * sF[2 * PLF + o] + sF[2 * PLF + o + 1] + wxp * sF[2 * PLF + o + 2];
                     }
 #pragma unroll
-                    for (int k = 0; k < PX; ++k) {
+                    for (int k = 0; k < PXB; ++k) {
                         int Y = Yb + k;
                         float wym = (Y == 1) ? 2.f : 1.f, wyp = (Y == H - 2) ? 2.f : 1.f;
                         float Sa = wym * ha[k] + ha[k + 1] + wyp * ha[k + 2];
                         float Sb = wym * hb[k] + hb[k + 1] + wyp * hb[k + 2];
                         float Sc = wym * hc[k] + hc[k + 1] + wyp * hc[k + 2];
-                        int o2 = (PX * ty + k + 2) * BW + tx + 2;
+                        int o2 = (PXB * ty + k + 2) * BW + tx + 2;
                         float xq = sX[ch * PLB + o2], yq = sT[ch * PLB + o2];
                         float g = Sa + Sb * xq + Sc * yq;
-                        if (((sSel[(PX * ty + k + 1) * FW + tx + 1] >> (2 * s)) & 3u) == want) g += w_l1 * sgn(xq - yq);
+                        if (((sSel[(PXB * ty + k + 1) * FW + tx + 1] >> (2 * s)) & 3u) == want) g += w_l1 * sgn(xq - yq);
                         dcol[k][ch] = g;
                     }
                 }
@@ -851,30 +845,26 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
 #pragma unroll
             for (int j = 0; j < NDP; ++j) dP[j] = 0.f;
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXB; ++k) {
                 int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
-                float du = sD[(PX * ty + k + 2) * BW + tx + 2];
+                if (CHAIN_DBG & 8) {
+                    dP[k] += dcol[k][0] + dcol[k][1] + dcol[k][2];
+                    continue;
+                }
+                float du = sD[(PXB * ty + k + 2) * BW + tx + 2];
                 float c0, c1, c2;
                 pixel_ray(cam, X, Y, c0, c1, c2);
                 Warp w;
-                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);
-                float gix = 0.f, giy = 0.f;
-                {
-                    f4 nw, ne, sw, se;
-                    gather_rgba(src4, W, w, nw, ne, sw, se);
-                    const f4 ddx = (ne - nw) * (1.f - w.ty) + (se - sw) * w.ty;
-                    const f4 ddy = (sw - nw) * (1.f - w.tx) + (se - ne) * w.tx;
+                warp_project(P, geo, frcp(geo.min_disp + geo.disp_range * du), c0, c1, c2, w);     // (arithmetic only: no gather)
+                // d ix / d u = mask (the (W-1)/2 and 2/(W-1) factors of unnormalise/normalise cancel); masks and 1 / z ride in tapd
+                float dp0 = 0.f, dp1 = 0.f;
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        gix += dcol[k][ch] * ddx[ch];
-                        giy += dcol[k][ch] * ddy[ch];
-                    }
+                for (int ch = 0; ch < 3; ++ch) {
+                    dp0 += dcol[k][ch] * tapd[k][ch][0];
+                    dp1 += dcol[k][ch] * tapd[k][ch][1];
                 }
-                // d ix / d u = mask (the (W-1)/2 and 2/(W-1) factors of unnormalise/normalise cancel)
-                float d_u = gix * w.mx, d_v = giy * w.my;
-                float dp0 = d_u * w.rden, dp1 = d_v * w.rden;
-                float dp2 = -(d_u * w.u + d_v * w.v) * w.rden;
+                float dp2 = -(dp0 * w.u + dp1 * w.v);
                 float X3 = w.depth * w.c0, Y3 = w.depth * w.c1, Z3 = w.depth * w.c2;
                 dP[0] += dp0 * X3; dP[1] += dp0 * Y3; dP[2] += dp0 * Z3; dP[3] += dp0;
                 dP[4] += dp1 * X3; dP[5] += dp1 * Y3; dP[6] += dp1 * Z3; dP[7] += dp1;
@@ -887,12 +877,14 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
             }
 #pragma unroll
             for (int j = 0; j < NDP; ++j) {
-                float v = dvs::wave_sum(dP[j]);
-                if (lane == 0) sRed[wave][j] = v;
+                float v = (CHAIN_DBG & 16) ? dP[j] : dvs::wave_sum_lane63(dP[j]);
+                if (lane == 63) sRed[wave][j] = v;
             }
             __syncthreads();
             if (tid < NDP) {
-                float v = sRed[0][tid] + sRed[1][tid] + sRed[2][tid] + sRed[3][tid];
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NWV; ++wv) v += sRed[wv][tid];
                 q.g.bwd_partials[((((size_t)b * ntiles + tile) * S + s) * 2 + f) * NDP + tid] = v;
             }
             __syncthreads();  // sX, sF, sRed reused by the next frame
@@ -908,10 +900,10 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
             float k_grad = gs / mean;
             float k_mean = (mean_raw >= 0.001f) ? -gs * (cx * st[2] + cy * st[3]) / (mean * mean) / hw : 0.f;
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXB; ++k) {
                 int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
-                int o = (PX * ty + k + 2) * BW + tx + 2;
+                int o = (PXB * ty + k + 2) * BW + tx + 2;
                 float d0 = sD[o];
                 float g = 0.f;
                 if (X < W - 1) g += cx * sgn(d0 - sD[o + 1]) * edge_weight<PLB>(sT, o, o + 1);
@@ -926,18 +918,18 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
         float* dd = q.g.d_disp[s] + (size_t)b * hs * ws;
         if (same_res) {
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXB; ++k) {
                 int Y = Yb + k;
                 if (X < W && Y < H) dd[Y * W + X] = gd[k];
             }
         } else {
             // accumulate the tile's low-res footprint in LDS (sAcc aliases sF: the frame loop has ended),
             // then one global atomic per touched low-res pixel
-            for (int i = tid; i < ACC_H * ACC_W; i += NT) sAcc[i] = 0.f;
+            for (int i = tid; i < ACC_H * ACC_W; i += NTB) sAcc[i] = 0.f;
             int ox = (int)fmaxf(rx * (X0 + 0.5f) - 0.5f, 0.f), oy = (int)fmaxf(ry * (Y0 + 0.5f) - 0.5f, 0.f);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < PX; ++k) {
+            for (int k = 0; k < PXB; ++k) {
                 int Y = Yb + k;
                 if (X >= W || Y >= H) continue;
                 float sy = fmaxf(ry * (Y + 0.5f) - 0.5f, 0.f), sx = fmaxf(rx * (X + 0.5f) - 0.5f, 0.f);
@@ -951,7 +943,7 @@ __global__ __launch_bounds__(NT, BWD_WAVES) void chain_bwd_kernel(ChainParams p,
                 atomicAdd(&sAcc[(y1 - oy) * ACC_W + (x1 - ox)], g * ly * lx);
             }
             __syncthreads();
-            for (int i = tid; i < ACC_H * ACC_W; i += NT) {
+            for (int i = tid; i < ACC_H * ACC_W; i += NTB) {
                 int ay = i / ACC_W, ax = i - ay * ACC_W;
                 float v = sAcc[i];
                 int yy = oy + ay, xx = ox + ax;
@@ -1078,7 +1070,7 @@ int dvs_chain_bwd(const dvs_chain_cfg* cfg, const dvs_chain_fwd_io* io, const dv
     q.g = *g;
     if (g->phase != 2) {
         dvs::ProfScope prof(dvs::SLOT_CHAIN_BWD, st);
-        hipLaunchKernelGGL(chain_bwd_kernel, dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(NT), 0, st, p, q);
+        hipLaunchKernelGGL((chain_bwd_kernel<BWD_NT, TH / (BWD_NT / 64)>), dim3(p.tiles_x, p.tiles_y, cfg->B), dim3(BWD_NT), 0, st, p, q);
     }
     if (g->phase != 1) hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3(cfg->B, 2), dim3(NT), 0, st, p, q);
     return dvs::check_launch("dvs_chain_bwd");
