@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64 first; see module docstri
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVS_LIB") or os.path.join(HERE, "libdvslam_hip.so")    # DVS_LIB: A/B builds (tools/build_variant.py)
 MAX_SCALES = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = C.c_void_p
 
@@ -110,6 +110,8 @@ _SIGNATURES = {
     "dvs_last_error": (C.c_char_p, []),
     "dvs_set_deterministic": (C.c_int, [C.c_int]),
     "dvs_get_deterministic": (C.c_int, []),
+    "dvs_set_precision": (C.c_int, [C.c_int]),
+    "dvs_get_precision": (C.c_int, []),
     "dvs_abi_version": (C.c_int, []),
     "dvs_arch": (C.c_char_p, []),
     "dvs_profile_enable": (C.c_int, [C.c_int]),
@@ -195,6 +197,24 @@ def deterministic():
     if _deterministic and _lib is not None and not _lib.dvs_get_deterministic():
         _lib.dvs_set_deterministic(1)           # DVS_DETERMINISTIC=1 from the environment: tell the library once it is loaded
     return _deterministic
+
+
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+def set_precision(name):
+    """Arithmetic of the implicit-GEMM convolutions (include/dvslam.h: dvs_set_precision): "fp32" (default, the parity mode) or
+    "bf16" (bf16 operands, fp32 accumulate: the opt-in counterpart of the reference's use_amp)."""
+    global _precision
+    check(lib().dvs_set_precision(PRECISIONS[name]), "dvs_set_precision")
+    _precision = name
+
+
+_precision = "fp32"
+
+
+def precision():
+    return _precision
 
 
 def check(rc, what):

@@ -212,6 +212,14 @@ def _packed_weight(w, weight):
 # ---- Winograd F(2x2, 3x3) path of the stride-1 3x3 BasicBlock convolutions (csrc/conv_wino.hip) ------------------------
 _WINO = os.environ.get("DVS_WINOGRAD", "1") != "0"
 _WINO_FORCE = os.environ.get("DVS_WINOGRAD", "1") == "force"       # take the Winograd kernels whatever the cost model says (tests)
+
+
+def _wino_on():
+    """The Winograd kernels are fp32 kernels: in the bf16 mode (_lib.set_precision) the direct kernels on the bf16 matrix cores
+    are faster than 2.25x fewer fp32 multiplies, so every 3x3 layer takes those."""
+    return _WINO and _lib._precision != "bf16"
+
+
 _wino_packed = {}   # weight.data_ptr() -> [u, u_flip, weight._version, shape, weakref]  (either operand may be None)
 
 
@@ -220,7 +228,7 @@ def wino_eligible(weight, stride, pad, reflect, act, x2, planar, scale):
     transform or activation, both channel counts multiples of 16 (the kernels' K chunking) and wide enough to fill the
     32-channel MFMA columns."""
     co, ci, kh, kw = weight.shape
-    return (_WINO and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not reflect and act is None and x2 is None
+    return (_wino_on() and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not reflect and act is None and x2 is None
             and not planar and scale is None and ci % 16 == 0 and co % 16 == 0 and ci >= 64 and co >= 64)
 
 
@@ -295,7 +303,7 @@ def wino_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale):
     """The decoder's wide Conv3x3 layers (ReflectionPad2d(1) + 3x3, ELU, optionally nearest-2x upsample (+ concat) in the
     gather; model/layers.py:26-41, model/depth_decoder.py:52-62) on the Winograd kernel's general gather."""
     co, ci, kh, kw = weight.shape
-    if not (_WINO and _WINO_DEC and kh == 3 and kw == 3 and stride == 1 and pad == 1 and reflect and act in (None, "elu")
+    if not (_wino_on() and _WINO_DEC and kh == 3 and kw == 3 and stride == 1 and pad == 1 and reflect and act in (None, "elu")
             and not planar and scale is None and ci % 16 == 0 and co % 16 == 0 and ci >= 64 and co >= 64):
         return False
     c1 = x.shape[1]
@@ -337,7 +345,7 @@ def wino_wgrad_eligible(weight_shape, x=None):
     has the output's spatial size for these stride-1 layers) -- larger ones keep the implicit-GEMM weight gradient."""
     co, ci = weight_shape[:2]
     fits = x is None or (x.numel() // x.shape[1] + x.shape[3] + 1) * max(co, ci) * 4 + 8192 < 2 ** 30
-    return _WINO_WGRAD and co % 32 == 0 and ci % 32 == 0 and fits
+    return _wino_on() and _WINO_WGRAD and co % 32 == 0 and ci % 32 == 0 and fits
 
 
 def conv3x3_wino_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
@@ -379,7 +387,7 @@ def wino_dec_wgrad_eligible(weight_shape, x, x2):
     co, ci = weight_shape[:2]
     c2 = x2.shape[1] if isinstance(x2, torch.Tensor) else 0
     up = 1 if x2 is None else 2
-    return (_WINO and _WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
+    return (_wino_on() and _WINO_WGRAD and _WINO_DEC_WGRAD and co % 32 == 0 and x.shape[1] % 32 == 0 and c2 % 32 == 0
             and x.shape[1] + c2 == ci and x.shape[2] * up >= 2 and x.shape[3] * up >= 2
             and (x.shape[0] * x.shape[2] * x.shape[3] * up * up + 3 * x.shape[3] * up + 3) * max(co, x.shape[1], c2) * 4 + 8192 < 2 ** 30)
 

@@ -75,6 +75,10 @@ struct ProfScope {
 // launches (float atomics on the output), BatchNorm partial sums added in one fixed order -- so that two runs take the same
 // ReLU / maxpool branches and their gradients differ by smooth rounding noise only.
 bool deterministic();
+// dvs_set_precision(1): the implicit-GEMM convolutions (forward, data and weight gradient) multiply on the bf16 matrix cores --
+// operands rounded to bf16 as they are staged into LDS, fp32 accumulation, fp32 tensors in HBM on both sides; everything else
+// (BatchNorm, the loss chain, the optimiser) is unchanged.  The opt-in mode behind the caller's `use_amp` (vo/train.py:44,177-185).
+bool precision_bf16();
 
 constexpr int kWave = 64;  // gfx950 wavefront
 

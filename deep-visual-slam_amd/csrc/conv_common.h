@@ -341,6 +341,34 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ As, const f
     }
 }
 
+// ---- bf16 operands (dvs_set_precision(1)): LDS tiles [rows][BK] of bf16 with 16 bytes of row pad (80-byte rows: the eight lanes a
+// ds_read_b128 serves together start 20 banks apart -- 0, 20, 8, 28, 16, 4, 24, 12 -- i.e. conflict-free), natural k order;
+// v_mfma_f32_32x32x16_bf16 takes A[row r][k = 8 h + j] / B[k = 8 h + j][col r] as one 16-byte read per operand and 16-k step.
+// The C/D map is the fp32 kernel's, so the epilogues are shared.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+constexpr int LDKH = BK + 8;    // padded LDS row (bf16 elements)
+__device__ __forceinline__ bf16x4 to_bf16(f32x4 v) {
+    return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // v_cvt_pk_bf16_f32 x 2 (round to nearest even)
+}
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_stage_bf16(const __bf16* __restrict__ As, const __bf16* __restrict__ Bs, int a_row0, int b_row0,
+                                                int lane, f32x16 (&acc)[TM][TN]) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < BK / 16; ++j) {
+        bf16x8 a[TM], b[TN];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[m] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + m * 32 + r) * LDKH + j * 16 + h * 8);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = *reinterpret_cast<const bf16x8*>(Bs + (b_row0 + n * 32 + r) * LDKH + j * 16 + h * 8);
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+}
+
 // Buffer-addressed LDS-DMA: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The per-lane byte offset (row, tap) is
 // loop-invariant, the per-stage part (channel block / weight column) is a scalar, and a lane that must contribute zeros
 // (padding, rows past the end) carries an offset beyond the descriptor's num_records: the hardware range check returns 0.

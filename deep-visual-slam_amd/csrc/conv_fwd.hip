@@ -216,7 +216,8 @@ __device__ __forceinline__ void conv_epilogue(const FwdParams& p, const ConvShap
 // NBUF = 2: double-buffered LDS, one barrier per K-step (2 workgroups / CU for the 128-wide tiles);
 // NBUF = 1: one LDS buffer, the next stage waits in registers, two barriers per K-step but half the LDS,
 //           so twice as many workgroups (waves per SIMD) hide each other's gather / barrier phases.
-template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
+// BF16: the same gathers, the operands rounded to bf16 in store_stage, tiles of LDKH bf16 per row, v_mfma_f32_32x32x16_bf16.
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF, bool BF16 = false>
 __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_VECS = BM / 32, B_VECS = BN / 32;       // 16-byte vectors per thread per stage
@@ -224,6 +225,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                               // [NBUF][BM][LDK]
     float* Bs = smem + NBUF * BM * LDK;             // [NBUF][BN][LDK]
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);   // BF16: [NBUF][BM][LDKH], [NBUF][BN][LDKH]
+    __bf16* Bh = Ah + NBUF * BM * LDKH;
 
     ConvShape s = p.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -362,7 +365,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
             if (MODE == IN_PLANAR) v = finalize_planar<FOLD>(ra[j], ra_mask[j], psc, psh);
             else if (MODE == IN_DGRAD) v = finalize_dgrad(ra[j], ry[j], re[j], ra_ok[j], p.t.dact);
             else v = finalize<FOLD>(ra[j], ra_ok[j], fsc, fsh, p.t.in_relu);
-            *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * j) * LDK + c4) = v;
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(Ah + (buf * BM + r0 + 32 * j) * LDKH + c4) = to_bf16(v);
+            else *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * j) * LDK + c4) = v;
         }
 #pragma unroll
         for (int j = 0; j < B_VECS; ++j) {
@@ -370,7 +374,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
             f32x4 v = rb[j];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
-            *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * j) * LDK + c4) = v;
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(Bh + (buf * BN + r0 + 32 * j) * LDKH + c4) = to_bf16(v);
+            else *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * j) * LDK + c4) = v;
         }
     };
 
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(NT) void conv_fwd_kernel(FwdParams p) {
         const int buf = (NBUF == 2) ? (kt & 1) : 0;
         const bool staged = !(p.dbg_nobarrier & 4);   // experiment bit 4: MFMA + LDS reads only
         if (staged && kt + 1 < KT) load_stage();      // global loads in flight during the MFMAs
-        mfma_stage<TM, TN>(As + buf * BM * LDK, Bs + buf * BN * LDK, wm * TM * 32, wn * TN * 32, lane, acc);
+        if constexpr (BF16) mfma_stage_bf16<TM, TN>(Ah + buf * BM * LDKH, Bh + buf * BN * LDKH, wm * TM * 32, wn * TN * 32, lane, acc);
+        else mfma_stage<TM, TN>(As + buf * BM * LDK, Bs + buf * BN * LDK, wm * TM * 32, wn * TN * 32, lane, acc);
         if (NBUF == 1 && !(p.dbg_nobarrier & 1)) __syncthreads();   // everyone is done reading the single buffer
         if (staged && kt + 1 < KT) store_stage((NBUF == 2) ? (buf ^ 1) : 0);
         if (!(p.dbg_nobarrier & 1)) __syncthreads();
@@ -413,7 +419,7 @@ int conv_nbuf() {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF, bool BF16 = false>
 void launch_buf(const FwdParams& p, hipStream_t st, int slot);
 
 // LDS-DMA kernel (conv_dma.h) whenever the gather needs no per-element arithmetic and a 32-k stage stays
@@ -511,6 +517,12 @@ template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(const FwdParams& p0, hipStream_t st, int slot) {
     FwdParams p = p0;
     if constexpr (!FOLD && MODE != IN_PLANAR) {
+        // dvs_set_precision(1): the register-staged kernel with bf16 tiles (the LDS-DMA path cannot convert on the way)
+        if (dvs::precision_bf16() && (p.s.Cin & 3) == 0) {
+            p.dbg_nobarrier = 0;
+            launch_buf<BM, BN, WM, WN, MODE, FOLD, 2, true>(p, st, slot);
+            return;
+        }
         if (dma_eligible<MODE, FOLD>(p)) {
             launch_dma<BM, BN, WM, WN, MODE>(p, st, slot);
             return;
@@ -522,7 +534,7 @@ void launch_cfg(const FwdParams& p0, hipStream_t st, int slot) {
     else launch_buf<BM, BN, WM, WN, MODE, FOLD, 1>(p, st, slot);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF>
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, int NBUF, bool BF16>
 void launch_buf(const FwdParams& p, hipStream_t st, int slot) {
     int M = p.s.B * p.s.Ho * p.s.Wo;
     dim3 grid((M + BM - 1) / BM, (p.s.Cout + BN - 1) / BN);
@@ -530,8 +542,9 @@ void launch_buf(const FwdParams& p, hipStream_t st, int slot) {
         int mc = p.s.B * ((p.s.Ho + 1) / 2) * ((p.s.Wo + 1) / 2);
         grid = dim3((mc + BM - 1) / BM, (p.s.Cout + BN - 1) / BN, 4);
     }
-    size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
-    auto kern = conv_fwd_kernel<BM, BN, WM, WN, MODE, FOLD, NBUF>;
+    size_t lds = BF16 ? (size_t)NBUF * (BM + BN) * LDKH * 2 : (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
+    if (BF16 && MODE == IN_DGRAD && lds < (size_t)2 * BM * sizeof(int)) lds = (size_t)2 * BM * sizeof(int);      // the row table of the epilogue
+    auto kern = conv_fwd_kernel<BM, BN, WM, WN, MODE, FOLD, NBUF, BF16>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -557,10 +570,11 @@ void launch_mode(const FwdParams& p, hipStream_t st, int slot) {
         // upconv_1_1's data gradient (N = 96 input channels): three 32-column tiles per wave instead of a 128-wide tile
         // that is one quarter padding
         static const bool n96 = [] { const char* e = getenv("DVS_CONV_N96"); return !(e && e[0] == '0'); }();
-        if (n96 && s.Cout == 96 && !dma_eligible<MODE, FOLD>(p)) {
+        if (n96 && s.Cout == 96 && (dvs::precision_bf16() || !dma_eligible<MODE, FOLD>(p))) {
             FwdParams q = p;
             q.dbg_nobarrier = 0;
-            if (conv_nbuf() == 2) launch_buf<128, 96, 4, 1, MODE, FOLD, 2>(q, st, slot);
+            if (dvs::precision_bf16()) launch_buf<128, 96, 4, 1, MODE, FOLD, 2, true>(q, st, slot);
+            else if (conv_nbuf() == 2) launch_buf<128, 96, 4, 1, MODE, FOLD, 2>(q, st, slot);
             else launch_buf<128, 96, 4, 1, MODE, FOLD, 1>(q, st, slot);
             return;
         }

@@ -89,14 +89,32 @@ __global__ __launch_bounds__(NT) void wgrad_reduce_kernel(const float* __restric
 }
 
 
-template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
+// BF16 (dvs_set_precision(1)): the tiles hold bf16, still [pixel][channel] -- the reduction index of this GEMM is the pixel, so both
+// operands of v_mfma_f32_32x32x16_bf16 (A[row co][k = 8 h + j], B[k = 8 h + j][col]) are k-strided in that image; they are fetched
+// with gfx950's transposed read `ds_read_b64_tr_b16` (per 16 lanes a block of 4 pixels x 16 channels, lane i receives channel i of
+// the four pixels; lane 4 q + p supplies the address of pixel q, channels 4 p ..): two reads per operand and 16-pixel step.  Row
+// strides are padded to 64 or 192 bytes modulo 256 so that the four pixel rows a 32-lane half reads land on disjoint banks.
+constexpr int tr_pad(int n) { return ((2 * n) % 256 == 64 || (2 * n) % 256 == 192) ? n : n + 32; }
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* lo, const __bf16* hi) {
+    using lds_ptr = __attribute__((address_space(3))) s16x4*;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(hi));
+    return __builtin_bit_cast(bf16x8, s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, bool FOLD, bool BF16 = false>
 __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int D_VECS = BM / 32, X_VECS = BN / 32;       // 16-byte vectors per thread per stage
     constexpr int DV = BM / 4, XV = BN / 4;                 // vectors per pixel row
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    __shared__ __attribute__((aligned(16))) float Ds[2][BP][BM];
-    __shared__ __attribute__((aligned(16))) float Xs[2][BP][BN];
+    constexpr int LDM = tr_pad(BM), LDN = tr_pad(BN);       // BF16: row strides (elements) of the two images
+    __shared__ __attribute__((aligned(16))) float Ds[2][BP][BF16 ? LDM / 2 : BM];      // (BF16: the same bytes hold [2][BP][LDM] bf16)
+    __shared__ __attribute__((aligned(16))) float Xs[2][BP][BF16 ? LDN / 2 : BN];
+    __bf16* const Dh = reinterpret_cast<__bf16*>(&Ds[0][0][0]);
+    __bf16* const Xh = reinterpret_cast<__bf16*>(&Xs[0][0][0]);
     // Gather-offset ring (all modes but the planar stem): the two divisions that turn a pixel index into (b, oy, ox)
     // and the padding / reflection / upsample arithmetic of a tap depend on the PIXEL and the TAP only, yet every
     // one of the Cin/4 lanes that fetch a slice of that pixel used to redo them every stage (~100 VALU per 16-byte
@@ -258,7 +276,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
                 float u = p.t.dact ? v[e] * act_grad_from_out(rdy[j][e], p.t.dact) : v[e];
                 v[e] = rd_ok[j] ? u : 0.f;
             }
-            *reinterpret_cast<f32x4*>(&Ds[buf][d_p0 + (NT / DV) * j][d_c]) = v;
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(Dh + (buf * BP + d_p0 + (NT / DV) * j) * LDM + d_c) = to_bf16(v);
+            else *reinterpret_cast<f32x4*>(&Ds[buf][d_p0 + (NT / DV) * j][d_c]) = v;
             bsum += v;
         }
 #pragma unroll
@@ -266,7 +285,8 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
             f32x4 v;
             if (MODE == IN_PLANAR) v = finalize_planar<FOLD>(rx[j], rx_mask[j], psc, psh);
             else v = finalize<FOLD>(rx[j], rx_ok[j], fsc, fsh, p.t.in_relu);
-            *reinterpret_cast<f32x4*>(&Xs[buf][x_p0 + (NT / XV) * j][x_c]) = v;
+            if constexpr (BF16) *reinterpret_cast<bf16x4*>(Xh + (buf * BP + x_p0 + (NT / XV) * j) * LDN + x_c) = to_bf16(v);
+            else *reinterpret_cast<f32x4*>(&Xs[buf][x_p0 + (NT / XV) * j][x_c]) = v;
         }
     };
 
@@ -307,6 +327,30 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
             if (ring_ok) load_stage_ring(mb + BP);
             else load_stage(mb + BP);
         }
+        if constexpr (BF16) {
+            // my block of a transposed read: pixel row (8 h + q) of the 16-pixel step, channels 16 (g & 1) + 4 pp .. of a 32-column tile
+            const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+            const int prow = 8 * (g >> 1) + q, pcol = 16 * (g & 1) + 4 * pp;
+#pragma unroll
+            for (int t = 0; t < BP / 16; ++t) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const __bf16* base = Dh + (buf * BP + 16 * t + prow) * LDM + wm * TM * 32 + m * 32 + pcol;
+                    a[m] = tr_frag(base, base + 4 * LDM);
+                }
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const __bf16* base = Xh + (buf * BP + 16 * t + prow) * LDN + wn * TN * 32 + n * 32 + pcol;
+                    b[n] = tr_frag(base, base + 4 * LDN);
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < BP / 2; ++t) {
             float a[TM], b[TN];
@@ -319,6 +363,7 @@ __global__ __launch_bounds__(NT) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
         }
         if (more) store_stage(buf ^ 1);
         __syncthreads();
@@ -638,6 +683,10 @@ void launch_cfg(WgradParams p, hipStream_t st, size_t* need = nullptr) {
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     prof.work(2.0 * M * p.s.Cout * k_real);
     if constexpr (!FOLD && MODE != IN_PLANAR) {
+        if (dvs::precision_bf16()) {       // bf16 tiles: the register-staged kernel (the LDS-DMA ones cannot convert on the way)
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD, true>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+            return;
+        }
         static const bool dma = [] { const char* e = getenv("DVS_CONV_DMA"); return !(e && e[0] == '0'); }();
         static const int dbg = dvs::experiment_flags("DVS_CONV_DEBUG_NOBARRIER");
         p.dbg = dbg & 4;

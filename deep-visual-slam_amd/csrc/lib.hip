@@ -62,6 +62,8 @@ namespace {
 std::atomic<bool> g_deterministic{false};
 }
 bool deterministic() { return g_deterministic.load(std::memory_order_relaxed); }
+std::atomic<int> g_precision{0};
+bool precision_bf16() { return g_precision.load(std::memory_order_relaxed) == 1; }
 void set_deterministic(bool on) { g_deterministic.store(on); }
 
 void prof_begin(int, hipStream_t st, hipEvent_t* start) {
@@ -168,7 +170,15 @@ int dvs_set_deterministic(int on) {
 
 int dvs_get_deterministic(void) { return dvs::deterministic() ? 1 : 0; }
 
-int dvs_abi_version(void) { return 7; }
+int dvs_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return DVS_ERR_INVALID;
+    dvs::g_precision.store(mode);
+    return DVS_OK;
+}
+
+int dvs_get_precision(void) { return dvs::g_precision.load(); }
+
+int dvs_abi_version(void) { return 8; }
 
 const char* dvs_arch(void) { return "gfx950"; }
 

@@ -15,7 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import gradsink, ops, zeropool
+from . import _lib, gradsink, ops, zeropool
 from .layers import SSIM, BackprojectDepth, Project3D
 
 
@@ -96,6 +96,11 @@ class MonodepthTrainer:
         self.max_depth = tr["max_depth"]
         self.use_compile = tr["use_compile"]   # accepted for compatibility; there is no tracing compiler here
         self.materialize_outputs = bool(tr.get("materialize_outputs", False))
+        # Opt-in (Train.amp_bf16 / DVS_AMP_BF16=1; off: this package computes in fp32 whatever autocast says, which is what
+        # every parity statement is made for): when the caller runs process_batch under torch.autocast -- the `use_amp` branch
+        # of vo/train.py:177-185 -- the implicit-GEMM convolutions of the step (and of its backward) multiply on the bf16 matrix
+        # cores (_lib.set_precision; fp32 tensors, fp32 accumulation, fp32 BatchNorm / loss chain / optimiser).
+        self.amp_bf16 = bool(tr.get("amp_bf16", os.environ.get("DVS_AMP_BF16", "0") == "1"))
         self.noise_seed = int(tr.get("noise_seed", 0))
         self._step = 0
         # DepthNet and PoseNet are independent until the loss chain joins them: PoseNet's forward -- and, because
@@ -145,6 +150,12 @@ class MonodepthTrainer:
             if isinstance(sample[key], torch.Tensor):
                 sample[key] = sample[key].to(self.device, non_blocking=True)
         gradsink.join()                                          # side-stream kernels of the previous step (every set's)
+        if self.amp_bf16:
+            # the mode of this step AND of its backward (the caller runs that outside, after leaving autocast); a trainer without
+            # the opt-in never touches the process-wide mode
+            want = "bf16" if (self.amp_bf16 and torch.is_autocast_enabled("cuda")) else "fp32"
+            if want != _lib.precision():
+                _lib.set_precision(want)
         zeropool.reset(sample[("target_image", 0)].device)      # one memset for the step's zero-filled scratch
         if self.arena is not None and torch.is_grad_enabled():
             self._arena_prepare()

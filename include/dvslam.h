@@ -54,6 +54,16 @@ const char* dvs_arch(void);
 int dvs_set_deterministic(int on);
 int dvs_get_deterministic(void);
 
+/* Arithmetic of the implicit-GEMM convolutions (ABI 8; process-wide, 0 by default).  mode 0: fp32 operands on the fp32 matrix
+ * cores -- the reference's default precision and what every parity statement of this library is made for.  mode 1: bf16 operands
+ * (rounded to nearest-even as they are staged into LDS), fp32 accumulation, fp32 tensors in HBM on both sides -- the counterpart
+ * of the reference's `use_amp` branch (vo/train.py:44,177-185: torch.autocast + GradScaler around the same modules); forward,
+ * data and weight gradient of dvs_conv2d_* take it, the Winograd / stem / thin / head kernels, BatchNorm, the loss chain and the
+ * optimiser stay fp32.  Results then differ from mode 0 by bf16 operand rounding (2^-9 relative per product, averaging down over
+ * K): separately toleranced in tests/test_bf16_gpu.py, never the headline precision. */
+int dvs_set_precision(int mode);
+int dvs_get_precision(void);
+
 /* Peak probes (ABI 7; measurement aids of bench.py's `measured_peaks`, timed by the caller with events on `stream`):
  *   dvs_peak_probe_mfma: one wave per SIMD on every CU runs 4 * iters independent v_mfma_f32_32x32x2_f32 from registers; *flops
  *                        (host) = the flops the launch executes.  scratch: any device buffer of >= 4 bytes (never written).

@@ -1,0 +1,142 @@
+"""The opt-in bf16 mode of the implicit-GEMM convolutions (dvs_set_precision(1); include/dvslam.h) -- the counterpart of the
+reference's `use_amp` branch (vo/train.py:44,177-185).  NOT the parity mode: its own tolerance table.
+
+What the mode computes is exactly specified -- every operand of the product rounded to bf16 (nearest even), exact products,
+fp32 accumulation -- so the kernels are checked against THAT, evaluated by torch in fp64 on bf16-rounded operands:
+
+    forward        y  = conv(bf16(x), bf16(w))                       2e-5 of the tensor max (fp32 summation order)
+    data gradient  dx = conv_transpose(bf16(dy), bf16(w))            1e-4
+    weight grad    dw = correlate(bf16(dy), bf16(x))                 1e-4
+
+and against the fp32 result, which bounds what the mode costs in accuracy (operand rounding 2^-9 relative per factor, averaging
+down over K): 1e-2 of the tensor max for single layers, 3e-2 on the loss of a whole training step.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def relmax(a, b):
+    a, b = a.detach(), b.detach()
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+def r16(t):
+    return t.detach().to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.fixture
+def bf16_mode():
+    from deep_visual_slam_amd import _lib
+    _lib.set_precision("bf16")
+    yield
+    _lib.set_precision("fp32")
+
+
+CASES = [
+    # name, B, Cin, Cout, k, stride, pad, reflect, H, W
+    ("3x3_s1_64", 2, 64, 64, 3, 1, 1, False, 24, 40),
+    ("3x3_s1_128", 2, 128, 128, 3, 1, 1, False, 15, 20),
+    ("3x3_s2", 2, 64, 128, 3, 2, 1, False, 24, 40),
+    ("1x1_s2", 2, 64, 128, 1, 2, 0, False, 24, 40),
+    ("3x3_deep", 3, 256, 512, 3, 1, 1, False, 9, 13),
+    ("1x1_gemm", 2, 512, 256, 1, 1, 0, False, 7, 9),
+    ("refl_wide", 2, 128, 64, 3, 1, 1, True, 12, 20),
+    ("refl_96", 2, 64, 96, 3, 1, 1, True, 12, 20),
+    ("odd_tail", 1, 20, 36, 3, 1, 1, False, 11, 17),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_matches_its_specification(gpu_device, bf16_mode, case):
+    from deep_visual_slam_amd import conv as DC
+    name, B, ci, co, k, s, p, refl, H, W = case
+    torch.manual_seed(0)
+    x = torch.randn(B, ci, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, ci, k, k, device=gpu_device) * (2.0 / (ci * k * k)) ** 0.5).contiguous(memory_format=CL).requires_grad_(True)
+    y = DC.conv2d(x, w, None, s, p, 1 if refl else 0, None)
+    cot = torch.randn_like(y)
+    dx, dw = torch.autograd.grad(y, [x, w], cot)
+
+    def ref(xv, wv, cv):
+        xv = xv.clone().requires_grad_(True)
+        wv = wv.clone().requires_grad_(True)
+        xx = F.pad(xv, (p,) * 4, mode="reflect") if refl else xv
+        yr = F.conv2d(xx, wv, None, s, 0 if refl else p)
+        return yr, xv, wv, cv
+
+    # the specification: bf16-rounded operands, exact arithmetic (fp64)
+    yr, xv, wv, _ = ref(r16(x), r16(w), None)
+    assert relmax(y, yr) < 2e-5, relmax(y, yr)
+    (dx_r,) = torch.autograd.grad(yr, [xv], r16(cot), retain_graph=True)        # dgrad: bf16(dy) x bf16(w)
+    # (ReflectionPad2d: the data-gradient gather adds the mirrored taps' dy values in fp32 BEFORE the bf16 rounding -- one product
+    # of bf16(dy_a + dy_b) instead of two -- so border pixels differ from the two-product specification by one operand rounding)
+    assert relmax(dx, dx_r) < (5e-3 if refl else 1e-4), relmax(dx, dx_r)
+    (dw_r,) = torch.autograd.grad(yr, [wv], r16(cot))                           # wgrad: bf16(dy) x bf16(x)
+    assert relmax(dw, dw_r) < 1e-4, relmax(dw, dw_r)
+    # the cost against fp32
+    yf, xf, wf, _ = ref(x.detach().double(), w.detach().double(), None)
+    gxf, gwf = torch.autograd.grad(yf, [xf, wf], cot.double())
+    assert relmax(y, yf) < 1e-2 and relmax(dx, gxf) < 1e-2 and relmax(dw, gwf) < 1e-2
+
+
+def test_decoder_block_bf16(gpu_device, bf16_mode):
+    """upsample ; cat ; ReflectionPad ; 3x3 ; ELU (model/depthnet.py:79-88) in the bf16 mode against fp32 torch."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(1)
+    B, c1, c2, co, H, W = 2, 256, 256, 128, 10, 14
+    xa = torch.randn(B, c1, H // 2, W // 2, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    xb = torch.randn(B, c2, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    w = (torch.randn(co, c1 + c2, 3, 3, device=gpu_device) * 0.03).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(co, device=gpu_device) * 0.1).requires_grad_(True)
+    cat = torch.cat([F.interpolate(xa, scale_factor=2, mode="nearest"), xb], 1)
+    y_ref = F.elu(F.conv2d(F.pad(cat, (1,) * 4, mode="reflect"), w, b))
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [xa, xb, w, b], cot)
+    y = DC.conv2d(xa, w, b, 1, 0, 1, "elu", x2=xb)
+    assert relmax(y, y_ref) < 1e-2
+    g = torch.autograd.grad(y, [xa, xb, w, b], cot)
+    for a, r, nm in zip(g, g_ref, ("dxa", "dxb", "dw", "db")):
+        assert a.shape == r.shape and relmax(a, r) < 1e-2, (nm, relmax(a, r))
+
+
+def test_bf16_statistics_epilogue(gpu_device, bf16_mode):
+    """The BatchNorm statistics the convolution's epilogue takes are sums of the values it STORES (fp32), also in the bf16 mode."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 20, 24, device=gpu_device).contiguous(memory_format=CL)
+    w = (torch.randn(128, 64, 3, 3, device=gpu_device) * 0.05).contiguous(memory_format=CL)
+    stats = torch.zeros(2, 128, device=gpu_device)
+    y = DC.conv2d_forward(x, w, None, 1, 1, False, None, stats=stats)
+    assert relmax(stats[0], y.double().sum((0, 2, 3))) < 1e-5
+    assert relmax(stats[1], (y.double() ** 2).sum((0, 2, 3))) < 1e-5
+
+
+def test_training_step_bf16_against_fp32(gpu_device):
+    """One whole training step (both networks, loss chain, backward) in the two modes from the same weights: the loss within 3e-2
+    relative, every network gradient within 0.2 of the fp32 gradient's norm in total (cosine > 0.98)."""
+    import sys
+    sys.path.insert(0, ".")
+    import bench
+    from deep_visual_slam_amd import _lib
+    out = {}
+    for mode in ("fp32", "bf16"):
+        _lib.set_precision(mode)
+        try:
+            torch.manual_seed(0)
+            trainer, flat, sync, opt, sample = bench.build_gpu(2, 4, gpu_device, 0)
+            _, losses = trainer.process_batch(sample)
+            losses["loss"].backward()
+            sync.finish()
+            torch.cuda.synchronize()
+            out[mode] = (float(losses["loss"]), flat.grads.detach().clone())
+            del trainer, flat, sync, opt, sample
+        finally:
+            _lib.set_precision("fp32")
+    (l32, g32), (l16, g16) = out["fp32"], out["bf16"]
+    assert abs(l16 - l32) / abs(l32) < 3e-2, (l16, l32)
+    cos = float((g16.double() @ g32.double()) / (g16.double().norm() * g32.double().norm()))
+    assert cos > 0.98, cos
