@@ -343,9 +343,6 @@ def dav2_side(device, with_cpu, batches=(1, 8)):
     matrix cores), seeded random weights; per-kernel-class HIP-event times give the MFMA rooflines of the attention kernel
     and of the GEMM / convolution launches.  CPU beside it: the oracle restatement of the same forward."""
     from deep_visual_slam_amd import dp
-    if args.precision != "fp32":
-        from deep_visual_slam_amd import _lib as _dvs_lib
-        _dvs_lib.set_precision(args.precision)
     from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
     torch.manual_seed(0)
     net = DepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384]).to(device).eval()
@@ -494,6 +491,9 @@ def main():
     if world > 1:
         dist.barrier()
     from deep_visual_slam_amd import dp
+    if args.precision != "fp32":
+        from deep_visual_slam_amd import _lib as _dvs_lib
+        _dvs_lib.set_precision(args.precision)
 
     comm = None
     # N > 1: the gradient buckets go through this repo's own RCCL C-ABI (include/dvslam_rccl.h, dp.RcclComm: a communicator on a

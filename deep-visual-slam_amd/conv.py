@@ -271,6 +271,58 @@ def _wino_weight(w, weight, flip):
     return ent[int(flip)]
 
 
+# ---- bf16 mode: the same layers on the patch kernel (csrc/conv_p16.hip) -------------------------------------------------------
+_P16 = os.environ.get("DVS_BF16_PATCH", "1") != "0"
+_p16_packed = {}    # weight.data_ptr() -> [pack, pack_flip, weight._version, shape, weakref]
+
+
+def p16_eligible(weight, stride, pad, reflect, act, x2, planar, scale):
+    """bf16 mode only: forward AND data gradient of this convolution run on the patch kernel -- 3x3, stride 1, zero pad 1, no
+    fused input transform / bias / activation, channel counts multiples of 64."""
+    co, ci, kh, kw = weight.shape
+    return (_P16 and _lib._precision == "bf16" and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not reflect and act is None
+            and x2 is None and not planar and scale is None and ci % 64 == 0 and co % 64 == 0)
+
+
+def _p16_weight(w, weight, flip):
+    """bf16 [9][K/16][N][16] operand of the patch kernel (flip: the data gradient's), kept until the weight changes (same keying
+    as _wino_weight)."""
+    ent = _p16_packed.get(weight.data_ptr())
+    if not (ent is not None and ent[4]() is weight and ent[2] == weight._version and ent[3] == tuple(weight.shape)):
+        if len(_p16_packed) > 1024:
+            for k in [k for k, e in _p16_packed.items() if e[4]() is None]:
+                del _p16_packed[k]
+        ent = [None, None, weight._version, tuple(weight.shape), weakref.ref(weight)]
+        _p16_packed[weight.data_ptr()] = ent
+    if ent[int(flip)] is None:
+        u = torch.empty(weight.numel(), device=weight.device, dtype=torch.bfloat16)
+        check(_lib.lib().dvs_conv3x3_bf16_pack(w.data_ptr(), u.data_ptr(), weight.shape[0], weight.shape[1], int(flip), _lib.stream()),
+              "dvs_conv3x3_bf16_pack")
+        ent[int(flip)] = u
+    return ent[int(flip)]
+
+
+def conv3x3_p16(x, weight, stats=None, stat_groups=0, flip=False, residual=None, stat_slots=1):
+    """y = conv3x3(x, weight) (stride 1, zero pad 1) with bf16 operands on the patch kernel; flip: the data gradient of that
+    convolution, x = dY [B,Cout,H,W] -> dX [B,Cin,H,W] (+ residual).  `weight` must be the parameter object itself."""
+    x, w = _nhwc(x), _nhwc(weight)
+    co, ci = weight.shape[:2]
+    k, n = (co, ci) if flip else (ci, co)
+    B, cx, H, W = x.shape
+    if cx != k:
+        raise _lib.DvsError("conv3x3_p16: input has %d channels, the operand expects %d" % (cx, k))
+    u = _p16_weight(w, weight, flip)
+    y = torch.empty((B, n, H, W), device=x.device, dtype=torch.float32, memory_format=CL)
+    if residual is not None:
+        residual = _nhwc(residual)
+        if tuple(residual.shape) != tuple(y.shape):
+            raise _lib.DvsError("conv3x3_p16: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    check(_lib.lib().dvs_conv3x3_bf16_fwd(x.data_ptr(), u.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(),
+                                          ptr(stats), stat_groups if stats is not None else 0, int(stat_slots), B, H, W, k, n, int(flip),
+                                          _lib.stream()), "dvs_conv3x3_bf16_fwd")
+    return y
+
+
 STAT_SLOTS = int(os.environ.get("DVS_WINO_STAT_SLOTS", "16"))     # copies of the statistics table the Winograd forward spreads its atomics over
 
 
@@ -530,13 +582,15 @@ class _Conv2d(torch.autograd.Function):
         ctx.wino = (wino_tail and wino_eligible(weight, stride, pad, reflect, None, x2, planar, scale) and x.shape[1] == weight.shape[1]
                     and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31      # 32-bit buffer offsets
                     and wino_pays(x.shape[0], x.shape[2], x.shape[3], weight.shape[1], weight.shape[0]))
+        ctx.p16 = (not ctx.wino and bias is None and act is None and p16_eligible(weight, stride, pad, reflect, None, x2, planar, scale)
+                   and x.shape[1] == weight.shape[1] and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
         up2 = 2 if x2 is not None else 1
         ctx.wino_dec = (not ctx.wino and not groups and wino_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale)
                         and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2
                         * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
                         and wino_pays(x.shape[0], up2 * x.shape[2], up2 * x.shape[3], weight.shape[1], weight.shape[0]))
         # the statistics epilogues end with same-address atomics: spread over STAT_SLOTS copies where the consumer adds them up
-        slots = STAT_SLOTS if (groups and slots_ok and STAT_SLOTS > 1 and not planar and (ctx.wino or _DIRECT_SLOTS)) else 1
+        slots = STAT_SLOTS if (groups and slots_ok and STAT_SLOTS > 1 and not planar and (ctx.wino or ctx.p16 or _DIRECT_SLOTS)) else 1
         if groups:
             shape = (2, weight.shape[0]) if groups == 1 else (groups, 2, weight.shape[0])
             stats = zeropool.zeros(((slots, groups) + shape[-2:]) if slots > 1 else shape, x.device)
@@ -544,6 +598,8 @@ class _Conv2d(torch.autograd.Function):
             stats = None
         if ctx.wino:
             y = conv3x3_wino(x, weight, stats, groups, bias=bias, relu=act == "relu", stat_slots=slots)
+        elif ctx.p16:
+            y = conv3x3_p16(x, weight, stats, groups, stat_slots=slots)
         elif ctx.wino_dec:
             y = conv3x3_wino_gen(x, x2, weight, bias, act, reflect=True)
         else:
@@ -614,6 +670,9 @@ class _Conv2d(torch.autograd.Function):
                       and weight.shape[0] % 32 == 0 and ctx.x_shape[2] >= 2)
             if ctx.wino:
                 dx = conv3x3_wino(dy, weight, flip=True, residual=dxa)       # + the skip path's gradient in the epilogue
+                dxa = None
+            elif ctx.p16 and _lib._precision == "bf16":
+                dx = conv3x3_p16(dy, weight, flip=True, residual=dxa)
                 dxa = None
             elif x2 is None:
                 if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:

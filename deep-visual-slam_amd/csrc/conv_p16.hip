@@ -1,0 +1,233 @@
+// a1-a3 in the opt-in bf16 mode (dvs_set_precision(1)): the stride-1, zero-pad-1 3x3 convolutions of the BasicBlocks -- forward and
+// data gradient -- on v_mfma_f32_32x32x16_bf16.
+//
+// The implicit-GEMM kernels (conv_fwd.hip) gather every (tap, 32-channel) slice of the im2col matrix separately: nine times the
+// loads and, with fp32 tensors in HBM, nine times the fp32 -> bf16 conversions.  At bf16 matrix rates (16x the fp32 rate) that
+// gather, not the arithmetic, is the kernel.  Here a workgroup owns an 8 x 16 patch of output pixels of one image: the 10 x 18
+// input patch (64 channels at a time) is read ONCE, rounded to bf16 and kept in LDS as [pixel][channel]; the A operand of every
+// tap is the same image read at a shifted pixel -- one ds_read_b128 per 32 x 16 fragment at a per-lane base + an immediate (no
+// address arithmetic in the loop; pixel rows are 144 bytes apart, so the eight lanes a b128 read serves together start on banks
+// 0, 36, 8, 44, ... -- conflict-free).  The B operand (weights, pre-packed bf16 [tap][k / 16][n][16] by p16_pack_kernel, a few
+// hundred KB that stay in L2) goes global -> registers, one coalesced 1 KB load per 32-column fragment and 16-k step.
+//
+//   A[row = pixel r of a 32-pixel m-tile (two patch rows)][k = 8 h + j]   B[k = 8 h + j][col = output channel]
+//   C/D: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)          (the fp32 kernels' map)
+//
+// Tensors stay fp32 in HBM on both sides; accumulation is fp32; the BatchNorm statistics are taken from the fp32 results as in
+// the fp32 kernels.  Data gradient: the same kernel over dY with the rotated / transposed pack (flip).
+// Replaces (in that mode) conv1 / conv2 of model/resnet_encoder.py's BasicBlocks (torchvision resnet18 layout).
+#include "conv_common.h"
+
+#include <cstdint>
+
+namespace {
+using namespace dvsconv;
+
+constexpr int PH = 8, PW = 16, IH = PH + 2, IW = PW + 2, NPIX = IH * IW;      // output patch, input patch (180 pixels)
+constexpr int CK = 64, LDP = CK + 8;                                           // channels per chunk, LDS pixel stride (elements)
+constexpr int NITEM = NPIX * (CK / 4), NLOAD = (NITEM + NT - 1) / NT;          // 16-byte staging items per chunk, per thread (12)
+constexpr unsigned OOB = 0x80000000u;                                          // voffset past every descriptor: the load returns 0
+
+struct P16Params {
+    const float* x;          // [B][H][W][K] fp32
+    const __bf16* w;         // [9][K / 16][N][16] bf16
+    const float* res;        // optional [B][H][W][N]: added to the result (a skip path's gradient)
+    float* y;                // [B][H][W][N]
+    float* stats;            // optional [slots][G][2][N]
+    int B, H, W, K, N;
+    int tiles_x, tiles_y;    // patches per image
+    int stat_split;          // images >= stat_split count into statistics group 1
+    int stat_mask, stat_stride;
+};
+
+// fp32 [N_w = Cout][3][3][Cin] -> bf16 [9][K / 16][N][16].  flip = 0: K = Cin, N = Cout, tap as stored; flip = 1 (data gradient):
+// K = Cout, N = Cin, tap 8 - t (the filter rotated by 180 degrees).  One thread per 16-element output row.
+__global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int flip) {
+    const int K = flip ? Cout : Cin, N = flip ? Cin : Cout;
+    const int rows = 9 * (K / 16) * N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const int n = i % N, k16 = (i / N) % (K / 16), t = i / (N * (K / 16));
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = 16 * k16 + j;
+        const float v = flip ? w[((size_t)k * 9 + (8 - t)) * Cin + n] : w[((size_t)n * 9 + t) * Cin + k];
+        if (j < 8) lo[j] = (__bf16)v;
+        else hi[j - 8] = (__bf16)v;
+    }
+    bf16x8* o = reinterpret_cast<bf16x8*>(out + (size_t)i * 16);
+    o[0] = lo;
+    o[1] = hi;
+}
+
+template <int TN>      // 32-column fragments per wave: the workgroup covers 64 TN output channels
+__global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2][NPIX * LDP];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int H = p.H, W = p.W, K = p.K, N = p.N;
+    const int nblk = N / (64 * TN);
+    const int bid = blockIdx.x, nb = bid % nblk, tile = bid / nblk;             // the channel blocks of a patch are neighbours (L2)
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int b = tile / tpi, trem = tile - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * PH, x0 = tx * PW, n0 = nb * 64 * TN;
+
+    // ---- staging items: item = tid + 256 j -> pixel item / 16 of the input patch, channels 4 (item % 16) .. of the chunk
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * K * 4), 0x00020000);
+    unsigned voff[NLOAD];
+    const int c4 = tid & 15, pix0 = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        const int pix = pix0 + 16 * j;
+        const int iy = pix / IW, ix = pix - iy * IW;
+        const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        voff[j] = ok ? (unsigned)((((b * H + gy) * W + gx) * K + 4 * c4) * 4) : OOB;
+    }
+    const int loff0 = pix0 * LDP + 4 * c4;                                     // LDS element of item j: loff0 + 16 j LDP
+    f32x4 st[NLOAD];
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j)
+            st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], c * CK * 4, 0));
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j)
+            if (pix0 + 16 * j < NPIX) *reinterpret_cast<bf16x4*>(&sP[buf][loff0 + 16 * j * LDP]) = to_bf16(st[j]);
+    };
+
+    // ---- operands
+    int a_base[2];                                                              // my row of the two m-tiles (two patch rows each)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a_base[tm] = (((wm * 2 + tm) * 2 + (r >> 4)) * IW + (r & 15)) * LDP + 8 * h;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (int)((size_t)9 * K * N * 2), 0x00020000);
+    const unsigned b_voff = (unsigned)(((n0 + wn * TN * 32 + r) * 16 + 8 * h) * 2);
+    const int tap_stride = K * N * 2, k16_stride = N * 32;                      // bytes of the pack per tap, per 16-k block
+    auto load_b = [&](int chunk, int tap, int c16, bf16x8 (&bq)[TN]) __attribute__((always_inline)) {
+        const int soff = tap * tap_stride + (chunk * (CK / 16) + c16) * k16_stride;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+            bq[tn] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, b_voff, soff + tn * 1024, 0));
+    };
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
+
+    const int nchunk = K / CK;
+    constexpr int STEPS = 9 * (CK / 16), DEPTH = 3;                             // 16-k steps per chunk; B operands fetched DEPTH steps ahead
+    load_chunk(0);
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        store_chunk(c & 1);
+        __syncthreads();                     // (the buffer written next time was last read two chunks ago: one barrier per chunk)
+        if (c + 1 < nchunk) load_chunk(c + 1);
+        const __bf16* P = sP[c & 1];
+        bf16x8 bq[DEPTH + 1][TN];
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) load_b(c, s / (CK / 16), s % (CK / 16), bq[s]);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int tap = s / (CK / 16), c16 = s % (CK / 16);
+            if (s + DEPTH < STEPS) load_b(c, (s + DEPTH) / (CK / 16), (s + DEPTH) % (CK / 16), bq[(s + DEPTH) % (DEPTH + 1)]);
+            bf16x8 a[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                a[tm] = *reinterpret_cast<const bf16x8*>(P + a_base[tm] + ((tap / 3) * IW + (tap % 3)) * LDP + 16 * c16);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bq[s % (DEPTH + 1)][tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: [+ residual], store, statistics.  Register i of m-tile mt <-> patch pixel (2 mt + (m >> 4), m & 15), m = (i & 3) + 8 (i >> 2) + 4 h
+    const bool want_stats = p.stats != nullptr;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * H * W * N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.res ? (int)((size_t)p.B * H * W * N * 4) : 0, 0x00020000);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int co = n0 + (wn * TN + tn) * 32 + r;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+            const int mt = wm * 2 + tm;
+            unsigned off[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int oy = y0 + 2 * mt + (m >> 4), ox = x0 + (m & 15);
+                off[i] = (oy < H && ox < W) ? (unsigned)((((b * H + oy) * W + ox) * N + co) * 4) : OOB;
+            }
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, off[i], 0, 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[tm][tn][i];
+                if (want_stats && off[i] != OOB) {
+                    ssum += v;
+                    ssq += v * v;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p.res ? v + rv[i] : v), yr, off[i], 0, 0);
+            }
+        }
+        if (want_stats) {
+            // (copies of the table: thousands of workgroups adding to the same 2 N addresses serialise in the L2, see conv_wino.hip)
+            float* stt = p.stats + (size_t)((int)blockIdx.x & p.stat_mask) * p.stat_stride + (b >= p.stat_split ? 2 * N : 0);
+            const float a2 = ssum + __shfl_xor(ssum, 32, 64), q2 = ssq + __shfl_xor(ssq, 32, 64);
+            if (h == 0) {
+                atomicAdd(stt + co, a2);
+                atomicAdd(stt + N + co, q2);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream) {
+    DVS_REQUIRE(w && out && Cout > 0 && Cin > 0, "dvs_conv3x3_bf16_pack: bad argument");
+    DVS_REQUIRE(Cout % 16 == 0 && Cin % 16 == 0, "dvs_conv3x3_bf16_pack: channel counts must be multiples of 16 (got %d, %d)", Cout, Cin);
+    const int K = flip ? Cout : Cin, N = flip ? Cin : Cout;
+    const int rows = 9 * (K / 16) * N;
+    hipLaunchKernelGGL(p16_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, static_cast<__bf16*>(out), Cout, Cin, flip);
+    return dvs::check_launch("dvs_conv3x3_bf16_pack");
+}
+
+int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, float* y, float* stats, int stat_groups, int stat_slots, int B,
+                         int H, int W, int K, int N, int as_dgrad, void* stream) {
+    DVS_REQUIRE(x && wpack && y && B > 0 && H > 0 && W > 0, "dvs_conv3x3_bf16_fwd: bad argument");
+    DVS_REQUIRE(K % CK == 0 && N % 64 == 0 && K > 0 && N > 0, "dvs_conv3x3_bf16_fwd: K %% 64 == 0 and N %% 64 == 0 (got %d, %d)", K, N);
+    DVS_REQUIRE(stat_slots >= 1 && stat_slots <= 64 && (stat_slots & (stat_slots - 1)) == 0, "dvs_conv3x3_bf16_fwd: stat_slots must be a power of two <= 64");
+    DVS_REQUIRE(stat_groups >= 0 && stat_groups <= 2 && (stat_groups != 2 || (B & 1) == 0), "dvs_conv3x3_bf16_fwd: stat_groups");
+    DVS_REQUIRE((double)B * H * W * (K > N ? K : N) * 4 < 2147483648.0, "dvs_conv3x3_bf16_fwd: tensors must be smaller than 2 GiB");
+    P16Params p{};
+    p.x = x; p.w = static_cast<const __bf16*>(wpack); p.res = res; p.y = y;
+    p.stats = stat_groups ? stats : nullptr;
+    p.B = B; p.H = H; p.W = W; p.K = K; p.N = N;
+    p.tiles_x = (W + PW - 1) / PW; p.tiles_y = (H + PH - 1) / PH;
+    p.stat_split = stat_groups == 2 ? B / 2 : B;
+    p.stat_mask = stat_slots - 1;
+    p.stat_stride = stat_groups * 2 * N;
+    const int tiles = B * p.tiles_x * p.tiles_y;
+    dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, (hipStream_t)stream);
+    prof.work(2.0 * B * H * W * (double)N * 9.0 * K);
+    if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv3x3_p16_kernel<1>), dim3(tiles * (N / 64)), dim3(NT), 0, (hipStream_t)stream, p);
+    return dvs::check_launch("dvs_conv3x3_bf16_fwd");
+}
+
+}  // extern "C"

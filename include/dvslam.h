@@ -213,6 +213,15 @@ int dvs_conv3x3_wino_fwd(const float* x, const float* u, const float* bias, cons
 int dvs_conv3x3_wino_fwd_slots(const float* x, const float* u, const float* bias, const float* res, float* y, float* stats,
                                int stat_groups, int stat_slots, int B, int H, int W, int Cin, int Cout, int relu, int as_dgrad,
                                void* stream);
+/*   bf16 mode (ABI 8, dvs_set_precision(1)): the stride-1 / zero-pad-1 3x3 convolution on v_mfma_f32_32x32x16_bf16 with the input
+ *   patch of a workgroup (8 x 16 output pixels + halo, 64 channels at a time) kept in LDS as bf16 -- every tap reads the same image
+ *   (csrc/conv_p16.hip).  dvs_conv3x3_bf16_pack: w fp32 [Cout][3][3][Cin] -> out bf16 [9][K/16][N][16] (9 K N 2 bytes); flip = 0:
+ *   K = Cin, N = Cout (forward); flip = 1: K = Cout, N = Cin, taps rotated (data gradient).  dvs_conv3x3_bf16_fwd: y [B,H,W,N] =
+ *   conv3x3(x [B,H,W,K]) [+ res]; stats / stat_groups / stat_slots as in dvs_conv3x3_wino_fwd_slots (fp32 sums of the fp32 results);
+ *   as_dgrad only labels the profile slot.  K % 64 == 0, N % 64 == 0, tensors < 2 GiB.  Same module as dvs_conv3x3_wino_fwd. */
+int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream);
+int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, float* y, float* stats, int stat_groups, int stat_slots, int B,
+                         int H, int W, int K, int N, int as_dgrad, void* stream);
 int dvs_conv2d_pack_wt(const float* w, float* wt, int Cout, int Cin, int kh, int kw, void* stream);
 /*   dvs_conv2d_pack_wt_batch: the same transpose for many weights in one launch.  `table` (device memory) = n_entries
  *   records { const float* w; float* wt; int Cout, Cin, taps, wg_begin; } (32 bytes each), wg_begin = number of

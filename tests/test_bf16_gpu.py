@@ -115,6 +115,33 @@ def test_bf16_statistics_epilogue(gpu_device, bf16_mode):
     assert relmax(stats[1], (y.double() ** 2).sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize("B,ci,co,H,W,groups,slots", [(2, 64, 64, 24, 40, 1, 1), (4, 64, 128, 15, 20, 2, 16), (3, 128, 64, 9, 13, 1, 4),
+                                                     (2, 512, 512, 15, 20, 2, 16), (1, 256, 256, 30, 40, 0, 1)])
+def test_patch_kernel_forward_stats_residual(gpu_device, bf16_mode, B, ci, co, H, W, groups, slots):
+    """csrc/conv_p16.hip directly: forward with the BatchNorm statistics ([slots][G][2][C], G = halves of the batch), the data
+    gradient form with a residual, image sizes that are not multiples of the 8 x 16 patch."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(4)
+    x = torch.randn(B, ci, H, W, device=gpu_device).contiguous(memory_format=CL)
+    w = (torch.randn(co, ci, 3, 3, device=gpu_device) * (2.0 / (ci * 9)) ** 0.5).contiguous(memory_format=CL)
+    stats = torch.zeros((slots, groups, 2, co) if slots > 1 else ((groups, 2, co) if groups == 2 else (2, co)), device=gpu_device) if groups else None
+    y = DC.conv3x3_p16(x, w, stats, groups, stat_slots=slots)
+    yr = F.conv2d(r16(x), r16(w), None, 1, 1)
+    assert relmax(y, yr) < 2e-5, relmax(y, yr)
+    if groups:
+        st = stats.double().sum(0) if slots > 1 else stats.double()
+        st = st.reshape(groups, 2, co)
+        for g in range(groups):
+            yy = y.double()[g * B // groups:(g + 1) * B // groups]
+            assert relmax(st[g, 0], yy.sum((0, 2, 3))) < 1e-5
+            assert relmax(st[g, 1], (yy ** 2).sum((0, 2, 3))) < 1e-5
+    dy = torch.randn(B, co, H, W, device=gpu_device).contiguous(memory_format=CL)
+    res = torch.randn(B, ci, H, W, device=gpu_device).contiguous(memory_format=CL)
+    dx = DC.conv3x3_p16(dy, w, flip=True, residual=res)
+    dxr = F.conv_transpose2d(r16(dy), r16(w), None, 1, 1) + res.double()
+    assert relmax(dx, dxr) < 1e-4, relmax(dx, dxr)
+
+
 def test_training_step_bf16_against_fp32(gpu_device):
     """One whole training step (both networks, loss chain, backward) in the two modes from the same weights: the loss within 3e-2
     relative, every network gradient within 0.2 of the fp32 gradient's norm in total (cosine > 0.98)."""

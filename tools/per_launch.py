@@ -10,7 +10,9 @@ log = os.path.join(tempfile.gettempdir(), "dvs_profile_%d.log" % os.getpid())
 os.environ["DVS_PROFILE_LOG"] = log
 import torch
 import bench
-from deep_visual_slam_amd import dp, gradsink
+from deep_visual_slam_amd import _lib, dp, gradsink
+if os.environ.get("DVS_PRECISION"):
+    _lib.set_precision(os.environ["DVS_PRECISION"])      # per-launch view of the bf16 mode: DVS_PRECISION=bf16
 
 dev = torch.device("cuda:0")
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 12
