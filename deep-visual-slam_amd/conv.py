@@ -323,6 +323,26 @@ def conv3x3_p16(x, weight, stats=None, stat_groups=0, flip=False, residual=None,
     return y
 
 
+_P16_WGS = int(os.environ.get("DVS_BF16_WGRAD_WGS", "0"))        # workgroups of the bf16 weight gradient (0: the library's default)
+
+
+def conv3x3_p16_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
+    """Weight gradient of the stride-1 / pad-1 3x3 convolution with bf16 operands (csrc/conv_p16.hip).  dw_out: gradient sink to
+    add into (returns None), else a zero-filled [Cout][kh][kw][Cin]-stored tensor of the weight's shape is returned."""
+    x, dy = _nhwc(x), _nhwc(dy)
+    co, ci = weight_shape[:2]
+    B, _, H, W = x.shape
+    if dw_out is not None:
+        if tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
+            raise _lib.DvsError("conv3x3_p16_wgrad: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
+        dw = dw_out
+    else:
+        dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
+    check(_lib.lib().dvs_conv3x3_bf16_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, ci, co, _P16_WGS, _lib.stream()),
+          "dvs_conv3x3_bf16_wgrad")
+    return None if dw_out is not None else dw
+
+
 STAT_SLOTS = int(os.environ.get("DVS_WINO_STAT_SLOTS", "16"))     # copies of the statistics table the Winograd forward spreads its atomics over
 
 
@@ -706,12 +726,15 @@ class _Conv2d(torch.autograd.Function):
                         and weight.shape[3] == 3 and act in (None, "elu", "relu") and (ACT[act] or not want_b)
                         and wino_dec_wgrad_eligible(weight.shape, x, x2)
                         and wino_dec_wgrad_pays(dy.shape[0], dy.shape[2], dy.shape[3], weight.shape[1], weight.shape[0]))
+            p16_w = ctx.p16 and _lib._precision == "bf16" and not ctx.has_bias and not _lib.deterministic()
             if side is None:
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, gradsink.cur_stream())
                     gradsink.note(ctx.bias_ref, gradsink.cur_stream())
                 if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
+                elif p16_w:
+                    dw = conv3x3_p16_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 elif wino_gen:
                     dw, db = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight), y_out=y,
                                                     act=act, want_bias=want_b, db_out=bsink_w)
@@ -734,6 +757,8 @@ class _Conv2d(torch.autograd.Function):
                 with (torch.cuda.stream(side) if (_WGRAD_ORDERED or _lib.deterministic()) else _lib.on_stream(side)):
                     if ctx.wino and wino_wgrad_eligible(weight.shape, x):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
+                    elif p16_w:
+                        conv3x3_p16_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
                     elif wino_gen:
                         conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, y_out=y, act=act, db_out=bsink_w)
                     else:

@@ -194,9 +194,161 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     }
 }
 
+// ---- weight gradient:  dw[co][tap][ci] += sum over pixels dY[p][co] * x[p + tap][ci]  (K = pixels) ---------------------------------
+// A workgroup owns a 32 x 32 block of (output channel, input channel) pairs for all nine taps and a range of 8 x 16 patches; the
+// four waves take two patch rows each (a patch row = 16 pixels = one k-step) and keep nine 32 x 32 accumulators (144 registers).
+// Both tiles sit in LDS as bf16 [pixel][32 channels] (64-byte pixel rows: the 4 pixels x 32 channels a 32-lane half reads
+// transposed are 256 contiguous bytes, every bank once) and both operands are k-strided in that image, so they are fetched with
+// ds_read_b64_tr_b16 (see conv_wgrad.hip): A = dY (rows = co) once per k-step, B = the x patch at the tap's shifted pixel, nine
+// times.  At the end the waves add their accumulators through LDS and the sum goes into dw with float atomics (36 KB per
+// workgroup: the reason the block is 32 x 32 -- a 64 x 64 block per workgroup means four times the atomic volume per launch).
+constexpr int WB = 32;                                   // channels per block side
+struct P16WgradParams {
+    const float* x;          // [B][H][W][Cin]
+    const float* dy;         // [B][H][W][Cout]
+    float* dw;               // [Cout][3][3][Cin]
+    int B, H, W, Cin, Cout;
+    int tiles_x, tiles_y, npatch, nblk_ci, nblocks, nsplit, per_split;
+};
+
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+__device__ __forceinline__ bf16x8 tr_pair(const __bf16* lo, const __bf16* hi) {
+    using lds_ptr = __attribute__((address_space(3))) s16x4*;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(hi));
+    return __builtin_bit_cast(bf16x8, s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+__global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p) {
+    constexpr int NDY = PH * PW, DY_IT = NDY * (WB / 4) / NT, X_IT = (NPIX * (WB / 4) + NT - 1) / NT;      // 4 and 6 staging items per thread
+    __shared__ __attribute__((aligned(16))) __bf16 sD[2][NDY * WB];
+    __shared__ __attribute__((aligned(16))) __bf16 sX[2][NPIX * WB];
+    __shared__ __attribute__((aligned(16))) float sR[4][16][64];                 // epilogue: one tap's tiles of the four waves
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+    // the blocks of one patch range run on one XCD (they read the same pixels: L2)
+    // (with fewer than eight ranges that rule would leave XCDs empty: plain order then -- workgroup i runs on XCD i % 8, so an XCD gets
+    // every eighth block: a few input-channel slices and all output-channel slices)
+    int block, split;
+    if (p.nsplit >= 8) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        block = slot % p.nblocks;
+        split = (slot / p.nblocks) * 8 + xcd;
+    } else {
+        block = blockIdx.x % p.nblocks;
+        split = blockIdx.x / p.nblocks;
+    }
+    if (split >= p.nsplit) return;
+    const int co0 = (block / p.nblk_ci) * WB, ci0 = (block % p.nblk_ci) * WB;
+    const int t_begin = split * p.per_split, t_end = min(p.npatch, t_begin + p.per_split);
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    const int c4 = tid & 7, pix0 = tid >> 3;                                     // item j: pixel pix0 + 32 j, channels 4 c4 ..
+    const int tpi = p.tiles_x * p.tiles_y;
+    f32x4 sd[DY_IT], sx[X_IT];
+    auto load_patch = [&](int t) __attribute__((always_inline)) {
+        const int b = t / tpi, trem = t - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int y0 = ty * PH, x0 = tx * PW;
+#pragma unroll
+        for (int j = 0; j < DY_IT; ++j) {
+            const int pix = pix0 + 32 * j, gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            const unsigned off = (gy < H && gx < W) ? (unsigned)((((b * H + gy) * W + gx) * Cout + co0 + 4 * c4) * 4) : OOB;
+            sd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int pix = pix0 + 32 * j, iy = pix / IW, ix = pix - iy * IW;
+            const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned off = ok ? (unsigned)((((b * H + gy) * W + gx) * Cin + ci0 + 4 * c4) * 4) : OOB;
+            sx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+    };
+    auto store_patch = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < DY_IT; ++j) *reinterpret_cast<bf16x4*>(&sD[buf][(pix0 + 32 * j) * WB + 4 * c4]) = to_bf16(sd[j]);
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j)
+            if (pix0 + 32 * j < NPIX) *reinterpret_cast<bf16x4*>(&sX[buf][(pix0 + 32 * j) * WB + 4 * c4]) = to_bf16(sx[j]);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // my block of a transposed read (see conv_wgrad.hip): pixel (8 h' + q) of the 16-pixel k-step, channels 16 (g & 1) + 4 pp ..
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 8 * (g >> 1) + q, tcol = 16 * (g & 1) + 4 * pp;
+
+    if (t_begin < t_end) load_patch(t_begin);
+    int buf = 0;
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+        store_patch(buf);
+        __syncthreads();                     // (buffer buf ^ 1 was last read one patch ago, and every wave has passed this barrier since)
+        if (t + 1 < t_end) load_patch(t + 1);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int py = 2 * wave + rr;                                        // my patch row = my k-step
+            const __bf16* dbase = &sD[buf][(py * PW + trow) * WB + tcol];
+            const bf16x8 a = tr_pair(dbase, dbase + 4 * WB);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const __bf16* xbase = &sX[buf][((py + tap / 3) * IW + (tap % 3) + trow) * WB + tcol];
+                const bf16x8 bfr = tr_pair(xbase, xbase + 4 * WB);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- the four waves' accumulators -> one sum per tap -> dw.  C/D map: column (ci) = lane & 31, row (co) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sR[wave][i][lane] = acc[tap][i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * wave + k;                                          // wave w adds registers 4 w .. 4 w + 3 of the four waves
+            const float v = sR[0][i][lane] + sR[1][i][lane] + sR[2][i][lane] + sR[3][i][lane];
+            const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(p.dw + ((size_t)co * 9 + tap) * Cin + ci0 + r, v);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups, void* stream) {
+    DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0, "dvs_conv3x3_bf16_wgrad: bad argument");
+    DVS_REQUIRE(Cin % WB == 0 && Cout % WB == 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_bf16_wgrad: channel counts must be multiples of 32 (got %d, %d)", Cin, Cout);
+    DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0, "dvs_conv3x3_bf16_wgrad: tensors must be smaller than 2 GiB");
+    P16WgradParams p{};
+    p.x = x; p.dy = dy; p.dw = dw; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_x = (W + PW - 1) / PW; p.tiles_y = (H + PH - 1) / PH;
+    p.npatch = B * p.tiles_x * p.tiles_y;
+    p.nblk_ci = Cin / WB;
+    p.nblocks = (Cout / WB) * p.nblk_ci;
+    const int target = target_workgroups > 0 ? target_workgroups : 512;
+    int nsplit = (target + p.nblocks - 1) / p.nblocks;
+    nsplit = nsplit < 1 ? 1 : (nsplit > p.npatch ? p.npatch : nsplit);
+    p.per_split = (p.npatch + nsplit - 1) / nsplit;
+    p.nsplit = (p.npatch + p.per_split - 1) / p.per_split;
+    const int grid = p.nsplit >= 8 ? p.nblocks * ((p.nsplit + 7) / 8) * 8 : p.nblocks * p.nsplit;
+    dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, (hipStream_t)stream);
+    prof.work(2.0 * B * H * W * (double)Cout * 9.0 * Cin);
+    hipLaunchKernelGGL(conv3x3_p16_wgrad_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
+    return dvs::check_launch("dvs_conv3x3_bf16_wgrad");
+}
 
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream) {
     DVS_REQUIRE(w && out && Cout > 0 && Cin > 0, "dvs_conv3x3_bf16_pack: bad argument");

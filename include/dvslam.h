@@ -219,6 +219,10 @@ int dvs_conv3x3_wino_fwd_slots(const float* x, const float* u, const float* bias
  *   K = Cin, N = Cout (forward); flip = 1: K = Cout, N = Cin, taps rotated (data gradient).  dvs_conv3x3_bf16_fwd: y [B,H,W,N] =
  *   conv3x3(x [B,H,W,K]) [+ res]; stats / stat_groups / stat_slots as in dvs_conv3x3_wino_fwd_slots (fp32 sums of the fp32 results);
  *   as_dgrad only labels the profile slot.  K % 64 == 0, N % 64 == 0, tensors < 2 GiB.  Same module as dvs_conv3x3_wino_fwd. */
+/*   dvs_conv3x3_bf16_wgrad: dw [Cout][3][3][Cin] += the weight gradient of that convolution from x [B,H,W,Cin] and dy [B,H,W,Cout], bf16
+ *   operands (both k-strided, fetched with ds_read_b64_tr_b16), fp32 accumulation, float atomics into dw (about target_workgroups
+ *   workgroups, 0 = default; a workgroup owns a 32 x 32 x 9 block and a range of patches).  Cin % 32 == 0, Cout % 32 == 0. */
+int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups, void* stream);
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream);
 int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, float* y, float* stats, int stat_groups, int stat_slots, int B,
                          int H, int W, int K, int N, int as_dgrad, void* stream);

@@ -140,6 +140,13 @@ def test_patch_kernel_forward_stats_residual(gpu_device, bf16_mode, B, ci, co, H
     dx = DC.conv3x3_p16(dy, w, flip=True, residual=res)
     dxr = F.conv_transpose2d(r16(dy), r16(w), None, 1, 1) + res.double()
     assert relmax(dx, dxr) < 1e-4, relmax(dx, dxr)
+    # weight gradient: bf16(dy) x bf16(x), into a zero-filled tensor and, a second time, on top of it (it ADDS)
+    dw = DC.conv3x3_p16_wgrad(x, dy, (co, ci, 3, 3))
+    wv = r16(w).requires_grad_(True)
+    (dwr,) = torch.autograd.grad(F.conv2d(r16(x), wv, None, 1, 1), [wv], r16(dy))
+    assert dw.shape == dwr.shape and relmax(dw, dwr) < 1e-4, relmax(dw, dwr)
+    DC.conv3x3_p16_wgrad(x, dy, (co, ci, 3, 3), dw_out=dw)
+    assert relmax(dw, 2 * dwr) < 1e-4
 
 
 def test_training_step_bf16_against_fp32(gpu_device):
