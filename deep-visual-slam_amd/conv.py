@@ -119,14 +119,16 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
 _prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape, weakref to the weight)
 
 
-def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0, wino=False):
+def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0, wino=False, p16=False):
     """Data gradient of ReflectionPad2d(1) + 3x3 stride-1 conv when dz is already the PRE-activation gradient: the
     gradient w.r.t. the padded input is a plain zero-padded correlation (the LDS-DMA kernel; no fold, no activation
     derivative in its gather), dvs_reflect_fold then folds the border back and splits / 2x2-sums for an upsample(+concat)
     input.  Returns dx, or (d coarse, d skip) as conv2d_dgrad does."""
     l = _lib.lib()
     B, Cin, H, W = x_shape
-    if wino:        # the same full correlation on the Winograd kernel (rotated / transposed filter operand)
+    if p16:         # bf16 mode: the full correlation on the patch kernel
+        g = conv3x3_p16_gen(dz, None, weight, reflect=False, full=True, flip=True)
+    elif wino:      # the same full correlation on the Winograd kernel (rotated / transposed filter operand)
         g = conv3x3_wino_gen(dz, None, weight, reflect=False, full=True, flip=True)
     else:
         g = conv2d_dgrad(dz, weight, (B, Cin, H + 2, W + 2), 1, 0, False, prepadded=True)    # [B, Cin, H+2, W+2] (NHWC memory)
@@ -320,6 +322,44 @@ def conv3x3_p16(x, weight, stats=None, stat_groups=0, flip=False, residual=None,
     check(_lib.lib().dvs_conv3x3_bf16_fwd(x.data_ptr(), u.data_ptr(), residual.data_ptr() if residual is not None else None, y.data_ptr(),
                                           ptr(stats), stat_groups if stats is not None else 0, int(stat_slots), B, H, W, k, n, int(flip),
                                           _lib.stream()), "dvs_conv3x3_bf16_fwd")
+    return y
+
+
+def p16_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale):
+    """bf16 mode only: the decoder's wide Conv3x3 layers (ReflectionPad2d(1) + 3x3 [+ ELU], optionally nearest-2x upsample (+ concat)
+    in the gather) on the patch kernel: every source and the output in 64-channel chunks."""
+    co, ci, kh, kw = weight.shape
+    if not (_P16 and _lib._precision == "bf16" and kh == 3 and kw == 3 and stride == 1 and pad == 1 and reflect and act in (None, "elu")
+            and not planar and scale is None and co % 64 == 0):
+        return False
+    c1 = x.shape[1]
+    if x2 is None:
+        return c1 == ci and c1 % 64 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2
+    if x2 is UPSAMPLE_ONLY:
+        return c1 == ci and c1 % 64 == 0
+    return c1 % 64 == 0 and x2.shape[1] % 64 == 0 and c1 + x2.shape[1] == ci
+
+
+def conv3x3_p16_gen(x, x2, weight, bias=None, act=None, reflect=True, full=False, flip=False):
+    """Patch kernel with the general gather (bf16 operands).  x2: None, UPSAMPLE_ONLY or the skip tensor (x is then the
+    half-resolution operand).  full: zero-padded full correlation, output [B, N, H+2, W+2] (with flip: the padded-domain data gradient)."""
+    x, w = _nhwc(x), _nhwc(weight)
+    co, ci = weight.shape[:2]
+    k, n = (co, ci) if flip else (ci, co)
+    up = x2 is not None
+    skip = _nhwc(x2) if isinstance(x2, torch.Tensor) else None
+    B, c1, hs, ws = x.shape
+    H, W = (2 * hs, 2 * ws) if up else (hs, ws)
+    c2 = skip.shape[1] if skip is not None else 0
+    if c1 + c2 != k or (skip is not None and tuple(skip.shape) != (B, c2, H, W)):
+        raise _lib.DvsError("conv3x3_p16_gen: operands %s / %s do not make the %d input channels at %dx%d"
+                            % (tuple(x.shape), None if skip is None else tuple(skip.shape), k, H, W))
+    u = _p16_weight(w, weight, flip)
+    Ho, Wo, org = (H + 2, W + 2, 2) if full else (H, W, 1)
+    y = torch.empty((B, n, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
+    check(_lib.lib().dvs_conv3x3_bf16_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, u.data_ptr(), ptr(bias), y.data_ptr(),
+                                          B, H, W, c1, c2, n, Ho, Wo, org, int(up), int(bool(reflect)), ACT[act], int(flip), _lib.stream()),
+          "dvs_conv3x3_bf16_gen")
     return y
 
 
@@ -605,6 +645,8 @@ class _Conv2d(torch.autograd.Function):
         ctx.p16 = (not ctx.wino and bias is None and act is None and p16_eligible(weight, stride, pad, reflect, None, x2, planar, scale)
                    and x.shape[1] == weight.shape[1] and x.numel() // x.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
         up2 = 2 if x2 is not None else 1
+        ctx.p16_dec = (not ctx.wino and not ctx.p16 and not groups and p16_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale)
+                       and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2 * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
         ctx.wino_dec = (not ctx.wino and not groups and wino_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale)
                         and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) * up2 * up2
                         * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31
@@ -620,6 +662,8 @@ class _Conv2d(torch.autograd.Function):
             y = conv3x3_wino(x, weight, stats, groups, bias=bias, relu=act == "relu", stat_slots=slots)
         elif ctx.p16:
             y = conv3x3_p16(x, weight, stats, groups, stat_slots=slots)
+        elif ctx.p16_dec:
+            y = conv3x3_p16_gen(x, x2, weight, bias, act, reflect=True)
         elif ctx.wino_dec:
             y = conv3x3_wino_gen(x, x2, weight, bias, act, reflect=True)
         else:
@@ -696,7 +740,7 @@ class _Conv2d(torch.autograd.Function):
                 dxa = None
             elif x2 is None:
                 if padded and ctx.x_shape[2] >= 3 and ctx.x_shape[3] >= 3:
-                    dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape, wino=ctx.wino_dec)
+                    dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape, wino=ctx.wino_dec, p16=ctx.p16_dec and _lib._precision == "bf16")
                 else:
                     dx = conv2d_dgrad(dy, weight, ctx.x_shape, stride, pad, reflect, y, act, residual=dxa)   # + the other paths' gradient
                     dxa = None
@@ -705,7 +749,8 @@ class _Conv2d(torch.autograd.Function):
                 # gradient of the nearest 2x upsample = 2x2 sum; of the concat = channel split: both done in
                 # the data-gradient kernel's epilogue (or, on the padded-domain path, in dvs_reflect_fold)
                 if padded:
-                    dx, dx2 = conv2d_dgrad_padded(dy, weight, (B, weight.shape[1], H, W), split_c1=C1, wino=ctx.wino_dec)
+                    dx, dx2 = conv2d_dgrad_padded(dy, weight, (B, weight.shape[1], H, W), split_c1=C1, wino=ctx.wino_dec,
+                                                  p16=ctx.p16_dec and _lib._precision == "bf16")
                 else:
                     dx, dx2 = conv2d_dgrad(dy, weight, (B, weight.shape[1], H, W), stride, pad, reflect, y, act, split_c1=C1)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):

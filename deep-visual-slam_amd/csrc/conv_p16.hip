@@ -38,6 +38,12 @@ struct P16Params {
     int tiles_x, tiles_y;    // patches per image
     int stat_split;          // images >= stat_split count into statistics group 1
     int stat_mask, stat_stride;
+    // GEN (the decoder's layers): logical input cat(x [, x2]) of K = C1 + C2 channels at H x W; x is [B][H/2][W/2][C1] when `up`
+    // (nearest 2x in the gather), x2 [B][H][W][C2]; reflect: ReflectionPad2d(1) instead of zeros; org = 1: y [B][H][W][N], org = 2: the
+    // full correlation y [B][H+2][W+2][N]; + bias, activation (0 none, 1 ReLU, 2 ELU)
+    const float* x2;
+    const float* bias;
+    int C1, up, reflect, org, Ho, Wo, act;
 };
 
 // fp32 [N_w = Cout][3][3][Cin] -> bf16 [9][K / 16][N][16].  flip = 0: K = Cin, N = Cout, tap as stored; flip = 1 (data gradient):
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__
     o[1] = hi;
 }
 
-template <int TN>      // 32-column fragments per wave: the workgroup covers 64 TN output channels
+template <int TN, bool GEN = false>      // TN: 32-column fragments per wave (the workgroup covers 64 TN output channels); GEN: see P16Params
 __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     __shared__ __attribute__((aligned(16))) __bf16 sP[2][NPIX * LDP];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -72,22 +78,41 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     const int tpi = p.tiles_x * p.tiles_y;
     const int b = tile / tpi, trem = tile - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     const int y0 = ty * PH, x0 = tx * PW, n0 = nb * 64 * TN;
+    const int Ho = GEN ? p.Ho : H, Wo = GEN ? p.Wo : W, org = GEN ? p.org : 1;
+    const int C1 = GEN ? p.C1 : K, C2 = K - C1;
+    const int Hs = (GEN && p.up) ? H >> 1 : H, Ws = (GEN && p.up) ? W >> 1 : W;             // geometry of source x
 
     // ---- staging items: item = tid + 256 j -> pixel item / 16 of the input patch, channels 4 (item % 16) .. of the chunk
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * K * 4), 0x00020000);
-    unsigned voff[NLOAD];
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * Hs * Ws * C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((GEN && C2) ? p.x2 : p.x), 0,
+                                                                          (GEN && C2) ? (int)((size_t)p.B * H * W * C2 * 4) : 0, 0x00020000);
+    unsigned voff[NLOAD], voff2[GEN ? NLOAD : 1];
     const int c4 = tid & 15, pix0 = tid >> 4;
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
         const int pix = pix0 + 16 * j;
         const int iy = pix / IW, ix = pix - iy * IW;
-        const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+        int gy = y0 - org + iy, gx = x0 - org + ix;
+        if (GEN && p.reflect) {                           // ReflectionPad2d(1): -1 -> 1, H -> H - 2 (H, W >= 2)
+            gy = gy < 0 ? -gy : gy >= H ? 2 * H - 2 - gy : gy;
+            gx = gx < 0 ? -gx : gx >= W ? 2 * W - 2 - gx : gx;
+        }
         const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        voff[j] = ok ? (unsigned)((((b * H + gy) * W + gx) * K + 4 * c4) * 4) : OOB;
+        const int sy = (GEN && p.up) ? gy >> 1 : gy, sx = (GEN && p.up) ? gx >> 1 : gx;
+        voff[j] = ok ? (unsigned)((((b * Hs + sy) * Ws + sx) * C1 + 4 * c4) * 4) : OOB;
+        if constexpr (GEN) voff2[j] = ok ? (unsigned)((((b * H + gy) * W + gx) * C2 + 4 * c4) * 4) : OOB;
     }
     const int loff0 = pix0 * LDP + 4 * c4;                                     // LDS element of item j: loff0 + 16 j LDP
     f32x4 st[NLOAD];
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        if constexpr (GEN) {
+            if (c * CK >= C1) {                           // (chunk-uniform: C1 % 64 == 0) this chunk lives in the skip tensor
+#pragma unroll
+                for (int j = 0; j < NLOAD; ++j)
+                    st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr2, voff2[j], (c * CK - C1) * 4, 0));
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NLOAD; ++j)
             st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], c * CK * 4, 0));
@@ -149,13 +174,14 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     }
 
     // ---- epilogue: [+ residual], store, statistics.  Register i of m-tile mt <-> patch pixel (2 mt + (m >> 4), m & 15), m = (i & 3) + 8 (i >> 2) + 4 h
-    const bool want_stats = p.stats != nullptr;
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * H * W * N * 4), 0x00020000);
+    const bool want_stats = !GEN && p.stats != nullptr;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * Ho * Wo * N * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.res ? (int)((size_t)p.B * H * W * N * 4) : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, p.res ? (int)((size_t)p.B * Ho * Wo * N * 4) : 0, 0x00020000);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int co = n0 + (wn * TN + tn) * 32 + r;
+        const float bv = (GEN && p.bias) ? p.bias[co] : 0.f;
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
@@ -165,7 +191,7 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
             for (int i = 0; i < 16; ++i) {
                 const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
                 const int oy = y0 + 2 * mt + (m >> 4), ox = x0 + (m & 15);
-                off[i] = (oy < H && ox < W) ? (unsigned)((((b * H + oy) * W + ox) * N + co) * 4) : OOB;
+                off[i] = (oy < Ho && ox < Wo) ? (unsigned)((((b * Ho + oy) * Wo + ox) * N + co) * 4) : OOB;
             }
             float rv[16];
             if (p.res) {
@@ -174,10 +200,15 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = acc[tm][tn][i];
+                float v = acc[tm][tn][i];
                 if (want_stats && off[i] != OOB) {
                     ssum += v;
                     ssq += v * v;
+                }
+                if constexpr (GEN) {
+                    v += bv;
+                    if (p.act == ACT_ELU) v = v > 0.f ? v : expm1f(v);
+                    else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, p.res ? v + rv[i] : v), yr, off[i], 0, 0);
             }
@@ -328,6 +359,31 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p)
 
 extern "C" {
 
+int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, const float* bias, float* y, int B, int H, int W, int C1, int C2,
+                         int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream) {
+    DVS_REQUIRE(x && wpack && y && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && N > 0, "dvs_conv3x3_bf16_gen: bad argument");
+    DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_bf16_gen: x2 and C2 go together");
+    DVS_REQUIRE(C1 % CK == 0 && C2 % CK == 0 && N % 64 == 0, "dvs_conv3x3_bf16_gen: C1, C2 and N must be multiples of 64 (got %d, %d, %d)", C1, C2, N);
+    DVS_REQUIRE((org == 1 && Ho == H && Wo == W) || (org == 2 && Ho == H + 2 && Wo == W + 2 && !reflect),
+                "dvs_conv3x3_bf16_gen: org 1 (same size) or 2 (full correlation, zero padding)");
+    DVS_REQUIRE(!reflect || (H >= 2 && W >= 2), "dvs_conv3x3_bf16_gen: ReflectionPad2d(1) needs H, W >= 2");
+    DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_bf16_gen: upsampled input has even H, W");
+    DVS_REQUIRE(act == 0 || act == ACT_RELU || act == ACT_ELU, "dvs_conv3x3_bf16_gen: activation %d (0, 1 = ReLU, 2 = ELU)", act);
+    const int K = C1 + C2;
+    DVS_REQUIRE((double)B * Ho * Wo * (K > N ? K : N) * 4 < 2147483648.0, "dvs_conv3x3_bf16_gen: tensors must be smaller than 2 GiB");
+    P16Params p{};
+    p.x = x; p.x2 = x2; p.w = static_cast<const __bf16*>(wpack); p.bias = bias; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.C1 = C1; p.up = upsample; p.reflect = reflect; p.org = org; p.Ho = Ho; p.Wo = Wo; p.act = act;
+    p.tiles_x = (Wo + PW - 1) / PW; p.tiles_y = (Ho + PH - 1) / PH;
+    p.stat_split = B;
+    const int tiles = B * p.tiles_x * p.tiles_y;
+    dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, (hipStream_t)stream);
+    prof.work(2.0 * B * H * W * (double)N * 9.0 * K);
+    if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((conv3x3_p16_kernel<1, true>), dim3(tiles * (N / 64)), dim3(NT), 0, (hipStream_t)stream, p);
+    return dvs::check_launch("dvs_conv3x3_bf16_gen");
+}
+
 int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups, void* stream) {
     DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0, "dvs_conv3x3_bf16_wgrad: bad argument");
     DVS_REQUIRE(Cin % WB == 0 && Cout % WB == 0 && Cin > 0 && Cout > 0, "dvs_conv3x3_bf16_wgrad: channel counts must be multiples of 32 (got %d, %d)", Cin, Cout);
@@ -371,6 +427,7 @@ int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, fl
     p.stats = stat_groups ? stats : nullptr;
     p.B = B; p.H = H; p.W = W; p.K = K; p.N = N;
     p.tiles_x = (W + PW - 1) / PW; p.tiles_y = (H + PH - 1) / PH;
+    p.C1 = K; p.org = 1; p.Ho = H; p.Wo = W;
     p.stat_split = stat_groups == 2 ? B / 2 : B;
     p.stat_mask = stat_slots - 1;
     p.stat_stride = stat_groups * 2 * N;
