@@ -297,7 +297,8 @@ def _p16_weight(w, weight, flip):
         ent = [None, None, weight._version, tuple(weight.shape), weakref.ref(weight)]
         _p16_packed[weight.data_ptr()] = ent
     if ent[int(flip)] is None:
-        u = torch.empty(weight.numel(), device=weight.device, dtype=torch.bfloat16)
+        k, n = (weight.shape[0], weight.shape[1]) if flip else (weight.shape[1], weight.shape[0])
+        u = torch.empty(9 * k * ((n + 31) // 32 * 32), device=weight.device, dtype=torch.bfloat16)      # (N padded to 32 columns)
         check(_lib.lib().dvs_conv3x3_bf16_pack(w.data_ptr(), u.data_ptr(), weight.shape[0], weight.shape[1], int(flip), _lib.stream()),
               "dvs_conv3x3_bf16_pack")
         ent[int(flip)] = u
@@ -326,18 +327,19 @@ def conv3x3_p16(x, weight, stats=None, stat_groups=0, flip=False, residual=None,
 
 
 def p16_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale):
-    """bf16 mode only: the decoder's wide Conv3x3 layers (ReflectionPad2d(1) + 3x3 [+ ELU], optionally nearest-2x upsample (+ concat)
-    in the gather) on the patch kernel: every source and the output in 64-channel chunks."""
+    """bf16 mode only: the decoder's Conv3x3 layers (ReflectionPad2d(1) + 3x3 [+ ELU], optionally nearest-2x upsample (+ concat) in
+    the gather) on the patch kernels: 64-channel chunks for the wide levels, the thin kernel (32 output channels per workgroup,
+    chunks of 32 / 16) for the 32- and 16-channel ones."""
     co, ci, kh, kw = weight.shape
     if not (_P16 and _lib._precision == "bf16" and kh == 3 and kw == 3 and stride == 1 and pad == 1 and reflect and act in (None, "elu")
-            and not planar and scale is None and co % 64 == 0):
+            and not planar and scale is None and co % 16 == 0):
         return False
     c1 = x.shape[1]
     if x2 is None:
-        return c1 == ci and c1 % 64 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2
+        return c1 == ci and c1 % 16 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2
     if x2 is UPSAMPLE_ONLY:
-        return c1 == ci and c1 % 64 == 0
-    return c1 % 64 == 0 and x2.shape[1] % 64 == 0 and c1 + x2.shape[1] == ci
+        return c1 == ci and c1 % 16 == 0
+    return c1 % 16 == 0 and x2.shape[1] % 16 == 0 and c1 + x2.shape[1] == ci
 
 
 def conv3x3_p16_gen(x, x2, weight, bias=None, act=None, reflect=True, full=False, flip=False):

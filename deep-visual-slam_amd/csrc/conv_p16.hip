@@ -48,8 +48,9 @@ struct P16Params {
 
 // fp32 [N_w = Cout][3][3][Cin] -> bf16 [9][K / 16][N][16].  flip = 0: K = Cin, N = Cout, tap as stored; flip = 1 (data gradient):
 // K = Cout, N = Cin, tap 8 - t (the filter rotated by 180 degrees).  One thread per 16-element output row.
+// (N is padded to a multiple of 32 with zero columns: the thin layers' 16 output channels still fill a 32-column fragment.)
 __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int Cout, int Cin, int flip) {
-    const int K = flip ? Cout : Cin, N = flip ? Cin : Cout;
+    const int K = flip ? Cout : Cin, Nr = flip ? Cin : Cout, N = (Nr + 31) / 32 * 32;
     const int rows = 9 * (K / 16) * N;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= rows) return;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int k = 16 * k16 + j;
-        const float v = flip ? w[((size_t)k * 9 + (8 - t)) * Cin + n] : w[((size_t)n * 9 + t) * Cin + k];
+        const float v = n >= Nr ? 0.f : flip ? w[((size_t)k * 9 + (8 - t)) * Cin + n] : w[((size_t)n * 9 + t) * Cin + k];
         if (j < 8) lo[j] = (__bf16)v;
         else hi[j - 8] = (__bf16)v;
     }
@@ -225,6 +226,127 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     }
 }
 
+// ---- thin layers (the decoder's 32- and 16-channel levels, both directions): 32 output channels per workgroup, channel chunks of 32
+// or 16.  In fp32 these layers sit at 2 - 5 x their HBM bound because the fp32 matrix rate is the vector rate; on the bf16 cores
+// the arithmetic is a tenth of the memory time.  Same patch scheme -- 8 x 32 output pixels (eight 32-pixel m-tiles, two per wave),
+// 10 x 34 input pixels -- with the chunk's WEIGHTS in LDS too (9 taps x CKT x 32 columns = 18 KB at CKT = 32): with one 32-column
+// fragment per wave a B operand from L2 would be re-fetched by every wave for every step.  One buffer, two barriers per chunk;
+// three workgroups per CU hide each other's staging.
+constexpr int TPH = 8, TPW = 32, TIH = TPH + 2, TIW = TPW + 2, TNPIX = TIH * TIW;          // 340 input pixels
+template <int CKT>
+__global__ __launch_bounds__(NT) void conv3x3_p16_thin_kernel(P16Params p) {
+    constexpr int LDT = CKT + 8;                                                 // 80 / 48 bytes per pixel: conflict-free b128 reads
+    constexpr int VPP = CKT / 4, PSTEP = NT / VPP;                               // 16-byte items per pixel, pixels per staging round
+    constexpr int NLD = (TNPIX + PSTEP - 1) / PSTEP;                             // staging rounds (11 / 6)
+    constexpr int WROWS = 9 * (CKT / 16) * 32, WLD = (WROWS * 2 + NT - 1) / NT;  // 32-byte weight rows of a chunk, 16-byte items per thread
+    __shared__ __attribute__((aligned(16))) __bf16 sP[TNPIX * LDT];
+    __shared__ __attribute__((aligned(16))) __bf16 sW[WROWS * 16];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, K = p.K, N = p.N, Np = (N + 31) / 32 * 32;
+    const int nblk = Np / 32;
+    const int bid = blockIdx.x, nb = bid % nblk, tile = bid / nblk;
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int b = tile / tpi, trem = tile - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * TPH, x0 = tx * TPW, n0 = nb * 32;
+    const int Ho = p.Ho, Wo = p.Wo, org = p.org;
+    const int C1 = p.C1, C2 = K - C1;
+    const int Hs = p.up ? H >> 1 : H, Ws = p.up ? W >> 1 : W;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * Hs * Ws * C1 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(C2 ? p.x2 : p.x), 0,
+                                                                          C2 ? (int)((size_t)p.B * H * W * C2 * 4) : 0, 0x00020000);
+    unsigned voff[NLD], voff2[NLD];
+    const int c4 = tid % VPP, pix0 = tid / VPP;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int pix = pix0 + PSTEP * j;
+        const int iy = pix / TIW, ix = pix - iy * TIW;
+        int gy = y0 - org + iy, gx = x0 - org + ix;
+        if (p.reflect) {
+            gy = gy < 0 ? -gy : gy >= H ? 2 * H - 2 - gy : gy;
+            gx = gx < 0 ? -gx : gx >= W ? 2 * W - 2 - gx : gx;
+        }
+        const bool ok = pix < TNPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const int sy = p.up ? gy >> 1 : gy, sx = p.up ? gx >> 1 : gx;
+        voff[j] = ok ? (unsigned)((((b * Hs + sy) * Ws + sx) * C1 + 4 * c4) * 4) : OOB;
+        voff2[j] = ok ? (unsigned)((((b * H + gy) * W + gx) * C2 + 4 * c4) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (int)((size_t)9 * K * Np * 2), 0x00020000);
+
+    int a_base[2];                                                               // m-tile = one patch row of 32 pixels
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) a_base[tm] = ((wave * 2 + tm) * TIW + r) * LDT + 8 * h;
+    const int b_base = (r * 16 + 8 * h);                                         // my column's 8 k of a 16-k block of sW
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[tm][i] = 0.f;
+
+    const int nchunk = K / CKT;
+#pragma unroll 1
+    for (int c = 0; c < nchunk; ++c) {
+        f32x4 st[NLD];
+        const bool second = c * CKT >= C1;                                       // (chunk-uniform: C1 % CKT == 0)
+        if (second) {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j)
+                st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr2, voff2[j], (c * CKT - C1) * 4, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], c * CKT * 4, 0));
+        }
+        // the chunk's weights: rows (tap, k16 of the chunk, column) of 32 bytes -> sW in the same order
+        f32x4 wv[WLD];
+#pragma unroll
+        for (int j = 0; j < WLD; ++j) {
+            const int it = tid + NT * j, row = it >> 1, half = it & 1;
+            const int col = row & 31, k16 = (row >> 5) % (CKT / 16), tap = row / (32 * (CKT / 16));
+            const unsigned off = it < WROWS * 2 ? (unsigned)((((tap * (K / 16) + c * (CKT / 16) + k16) * Np + n0 + col) * 16 + 8 * half) * 2) : OOB;
+            wv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+        }
+        if (c > 0) __syncthreads();                                              // everyone is done reading the previous chunk
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (pix0 + PSTEP * j < TNPIX) *reinterpret_cast<bf16x4*>(&sP[(pix0 + PSTEP * j) * LDT + 4 * c4]) = to_bf16(st[j]);
+#pragma unroll
+        for (int j = 0; j < WLD; ++j)
+            if (tid + NT * j < WROWS * 2) *reinterpret_cast<f32x4*>(&sW[(tid + NT * j) * 8]) = wv[j];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 9 * (CKT / 16); ++s) {
+            const int tap = s / (CKT / 16), c16 = s % (CKT / 16);
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&sW[s * 32 * 16 + b_base]);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&sP[a_base[tm] + ((tap / 3) * TIW + (tap % 3)) * LDT + 16 * c16]);
+                acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr, acc[tm], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: + bias, activation, store.  Register i of m-tile mt <-> patch pixel (mt, (i & 3) + 8 (i >> 2) + 4 h)
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.B * Ho * Wo * N * 4), 0x00020000);
+    const int co = n0 + r;
+    const bool co_ok = co < N;
+    const float bv = (p.bias && co_ok) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const int oy = y0 + wave * 2 + tm;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ox = x0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            const unsigned off = (co_ok && oy < Ho && ox < Wo) ? (unsigned)((((b * Ho + oy) * Wo + ox) * N + co) * 4) : OOB;
+            float v = acc[tm][i] + bv;
+            if (p.act == ACT_ELU) v = v > 0.f ? v : expm1f(v);
+            else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, off, 0, 0);
+        }
+    }
+}
+
 // ---- weight gradient:  dw[co][tap][ci] += sum over pixels dY[p][co] * x[p + tap][ci]  (K = pixels) ---------------------------------
 // A workgroup owns a 32 x 32 block of (output channel, input channel) pairs for all nine taps and a range of 8 x 16 patches; the
 // four waves take two patch rows each (a patch row = 16 pixels = one k-step) and keep nine 32 x 32 accumulators (144 registers).
@@ -363,7 +485,9 @@ int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, con
                          int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream) {
     DVS_REQUIRE(x && wpack && y && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && N > 0, "dvs_conv3x3_bf16_gen: bad argument");
     DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_bf16_gen: x2 and C2 go together");
-    DVS_REQUIRE(C1 % CK == 0 && C2 % CK == 0 && N % 64 == 0, "dvs_conv3x3_bf16_gen: C1, C2 and N must be multiples of 64 (got %d, %d, %d)", C1, C2, N);
+    const bool big = C1 % CK == 0 && C2 % CK == 0 && N % 64 == 0;
+    DVS_REQUIRE(big || (C1 % 16 == 0 && C2 % 16 == 0 && N % 16 == 0),
+                "dvs_conv3x3_bf16_gen: C1, C2 and N must be multiples of 16 (got %d, %d, %d)", C1, C2, N);
     DVS_REQUIRE((org == 1 && Ho == H && Wo == W) || (org == 2 && Ho == H + 2 && Wo == W + 2 && !reflect),
                 "dvs_conv3x3_bf16_gen: org 1 (same size) or 2 (full correlation, zero padding)");
     DVS_REQUIRE(!reflect || (H >= 2 && W >= 2), "dvs_conv3x3_bf16_gen: ReflectionPad2d(1) needs H, W >= 2");
@@ -374,11 +498,18 @@ int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, con
     P16Params p{};
     p.x = x; p.x2 = x2; p.w = static_cast<const __bf16*>(wpack); p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.C1 = C1; p.up = upsample; p.reflect = reflect; p.org = org; p.Ho = Ho; p.Wo = Wo; p.act = act;
-    p.tiles_x = (Wo + PW - 1) / PW; p.tiles_y = (Ho + PH - 1) / PH;
     p.stat_split = B;
-    const int tiles = B * p.tiles_x * p.tiles_y;
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, (hipStream_t)stream);
     prof.work(2.0 * B * H * W * (double)N * 9.0 * K);
+    if (!big) {          // thin layers: 32 output channels per workgroup, chunks of 32 (or 16) channels, 8 x 32 patches
+        p.tiles_x = (Wo + TPW - 1) / TPW; p.tiles_y = (Ho + TPH - 1) / TPH;
+        const int grid = B * p.tiles_x * p.tiles_y * ((N + 31) / 32);
+        if (C1 % 32 == 0 && C2 % 32 == 0) hipLaunchKernelGGL((conv3x3_p16_thin_kernel<32>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv3x3_p16_thin_kernel<16>), dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
+        return dvs::check_launch("dvs_conv3x3_bf16_gen");
+    }
+    p.tiles_x = (Wo + PW - 1) / PW; p.tiles_y = (Ho + PH - 1) / PH;
+    const int tiles = B * p.tiles_x * p.tiles_y;
     if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv3x3_p16_kernel<1, true>), dim3(tiles * (N / 64)), dim3(NT), 0, (hipStream_t)stream, p);
     return dvs::check_launch("dvs_conv3x3_bf16_gen");
@@ -409,7 +540,7 @@ int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, in
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream) {
     DVS_REQUIRE(w && out && Cout > 0 && Cin > 0, "dvs_conv3x3_bf16_pack: bad argument");
     DVS_REQUIRE(Cout % 16 == 0 && Cin % 16 == 0, "dvs_conv3x3_bf16_pack: channel counts must be multiples of 16 (got %d, %d)", Cout, Cin);
-    const int K = flip ? Cout : Cin, N = flip ? Cin : Cout;
+    const int K = flip ? Cout : Cin, N = ((flip ? Cin : Cout) + 31) / 32 * 32;
     const int rows = 9 * (K / 16) * N;
     hipLaunchKernelGGL(p16_pack_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, static_cast<__bf16*>(out), Cout, Cin, flip);
     return dvs::check_launch("dvs_conv3x3_bf16_pack");

@@ -103,6 +103,54 @@ def test_decoder_block_bf16(gpu_device, bf16_mode):
         assert a.shape == r.shape and relmax(a, r) < 1e-2, (nm, relmax(a, r))
 
 
+THIN = [
+    # c1, c2 (None: no skip; 0: upsample only), co, H, W (of the output), act
+    (64, None, 32, 24, 40, "elu"),       # upconv_1_0
+    (32, 64, 32, 24, 80, "elu"),         # upconv_1_1: cat(up(32), 64)
+    (32, None, 16, 17, 45, "elu"),       # upconv_0_0 (odd sizes)
+    (16, 0, 16, 36, 66, "elu"),          # upconv_0_1: upsample only
+    (48, None, 32, 9, 33, None),         # 16-channel chunks
+]
+
+
+@pytest.mark.parametrize("c1,c2,co,H,W,act", THIN, ids=["%s_%s_%s" % (c[0], c[1], c[2]) for c in THIN])
+def test_thin_decoder_layers_bf16(gpu_device, bf16_mode, c1, c2, co, H, W, act):
+    """The decoder's 32- / 16-channel levels (model/depth_decoder.py:52-62) on the thin patch kernel: forward against the bf16
+    specification, gradients against fp32 torch."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(5)
+    B = 2
+    up = c2 is not None
+    xa = torch.randn(B, c1, H // 2 if up else H, W // 2 if up else W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True)
+    xb = (torch.randn(B, c2, H, W, device=gpu_device).contiguous(memory_format=CL).requires_grad_(True) if c2 else None)
+    ci = c1 + (c2 or 0)
+    w = (torch.randn(co, ci, 3, 3, device=gpu_device) * (2.0 / (ci * 9)) ** 0.5).contiguous(memory_format=CL).requires_grad_(True)
+    b = (torch.randn(co, device=gpu_device) * 0.1).requires_grad_(True)
+
+    def ref(xa_, xb_, w_, b_):
+        t = F.interpolate(xa_, scale_factor=2, mode="nearest") if up else xa_
+        if xb_ is not None:
+            t = torch.cat([t, xb_], 1)
+        y_ = F.conv2d(F.pad(t, (1,) * 4, mode="reflect"), w_, b_)
+        return F.elu(y_) if act == "elu" else y_
+
+    if not up:
+        y = DC.conv2d(xa, w, b, 1, 1, 1, act)
+    elif c2:
+        y = DC.conv2d(xa, w, b, 1, 0, 1, act, x2=xb)
+    else:
+        y = DC.conv2d(xa, w, b, 1, 0, 1, act, upsample=True)
+    y_spec = ref(r16(xa), r16(xb) if xb is not None else None, r16(w), b.detach().double())
+    assert y.shape == y_spec.shape and relmax(y, y_spec) < 2e-5, relmax(y, y_spec)
+    y_ref = ref(xa, xb, w, b)
+    cot = torch.randn_like(y_ref)
+    ins = [xa] + ([xb] if xb is not None else []) + [w, b]
+    g_ref = torch.autograd.grad(y_ref, ins, cot)
+    g = torch.autograd.grad(y, ins, cot)
+    for a, r_, nm in zip(g, g_ref, ("dxa", "dxb", "dw", "db") if xb is not None else ("dxa", "dw", "db")):
+        assert a.shape == r_.shape and relmax(a, r_) < 1e-2, (nm, relmax(a, r_))
+
+
 def test_bf16_statistics_epilogue(gpu_device, bf16_mode):
     """The BatchNorm statistics the convolution's epilogue takes are sums of the values it STORES (fp32), also in the bf16 mode."""
     from deep_visual_slam_amd import conv as DC
