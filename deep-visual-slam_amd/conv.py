@@ -119,7 +119,7 @@ def conv2d_forward(x, weight, bias=None, stride=1, pad=0, reflect=False, act=Non
 _prepacked = {}     # weight.data_ptr() -> (packed tensor, weight._version it was packed at, shape, weakref to the weight)
 
 
-def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0, wino=False, p16=False):
+def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0, wino=False, p16=False, y_out=None, act=None):
     """Data gradient of ReflectionPad2d(1) + 3x3 stride-1 conv when dz is already the PRE-activation gradient: the
     gradient w.r.t. the padded input is a plain zero-padded correlation (the LDS-DMA kernel; no fold, no activation
     derivative in its gather), dvs_reflect_fold then folds the border back and splits / 2x2-sums for an upsample(+concat)
@@ -127,7 +127,8 @@ def conv2d_dgrad_padded(dz, weight, x_shape, split_c1=0, wino=False, p16=False):
     l = _lib.lib()
     B, Cin, H, W = x_shape
     if p16:         # bf16 mode: the full correlation on the patch kernel
-        g = conv3x3_p16_gen(dz, None, weight, reflect=False, full=True, flip=True)
+        # (y_out / act: dz is still dY, the thin kernel multiplies by act'(y_out) as it stages)
+        g = conv3x3_p16_gen(dz, None, weight, reflect=False, full=True, flip=True, dact_y=y_out, dact=act)
     elif wino:      # the same full correlation on the Winograd kernel (rotated / transposed filter operand)
         g = conv3x3_wino_gen(dz, None, weight, reflect=False, full=True, flip=True)
     else:
@@ -342,7 +343,7 @@ def p16_dec_eligible(weight, stride, pad, reflect, act, x, x2, planar, scale):
     return c1 % 16 == 0 and x2.shape[1] % 16 == 0 and c1 + x2.shape[1] == ci
 
 
-def conv3x3_p16_gen(x, x2, weight, bias=None, act=None, reflect=True, full=False, flip=False):
+def conv3x3_p16_gen(x, x2, weight, bias=None, act=None, reflect=True, full=False, flip=False, dact_y=None, dact=None):
     """Patch kernel with the general gather (bf16 operands).  x2: None, UPSAMPLE_ONLY or the skip tensor (x is then the
     half-resolution operand).  full: zero-padded full correlation, output [B, N, H+2, W+2] (with flip: the padded-domain data gradient)."""
     x, w = _nhwc(x), _nhwc(weight)
@@ -360,7 +361,9 @@ def conv3x3_p16_gen(x, x2, weight, bias=None, act=None, reflect=True, full=False
     Ho, Wo, org = (H + 2, W + 2, 2) if full else (H, W, 1)
     y = torch.empty((B, n, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=CL)
     check(_lib.lib().dvs_conv3x3_bf16_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, u.data_ptr(), ptr(bias), y.data_ptr(),
-                                          B, H, W, c1, c2, n, Ho, Wo, org, int(up), int(bool(reflect)), ACT[act], int(flip), _lib.stream()),
+                                          B, H, W, c1, c2, n, Ho, Wo, org, int(up), int(bool(reflect)), ACT[act], int(flip),
+                                          _nhwc(dact_y).data_ptr() if dact_y is not None else None, ACT[dact] if dact_y is not None else 0,
+                                          _lib.stream()),
           "dvs_conv3x3_bf16_gen")
     return y
 
@@ -734,7 +737,18 @@ class _Conv2d(torch.autograd.Function):
             B = ctx.x_shape[0]
             padded = (_PADDED and preact and reflect and stride == 1 and pad == 1 and weight.shape[2] == 3
                       and weight.shape[0] % 32 == 0 and ctx.x_shape[2] >= 2)
-            if ctx.wino:
+            # bf16 mode, thin decoder layers (no pre-activation pass): padded-domain gradient on the thin patch kernel with the
+            # activation derivative fused into its staging, then the reflection fold / upsample split
+            p16_thin = (ctx.p16_dec and _lib._precision == "bf16" and not preact and reflect and stride == 1 and pad == 1
+                        and (weight.shape[0] % 64 != 0 or weight.shape[1] % 64 != 0) and ctx.x_shape[2] >= 2 and dxa is None)
+            if p16_thin:
+                yk = dict(y_out=y, act=act) if ACT[act] else {}
+                if x2 is None:
+                    dx = conv2d_dgrad_padded(dy, weight, ctx.x_shape, p16=True, **yk)
+                else:
+                    dx, dx2 = conv2d_dgrad_padded(dy, weight, (B, weight.shape[1], 2 * ctx.x_shape[2], 2 * ctx.x_shape[3]),
+                                                  split_c1=ctx.x_shape[1], p16=True, **yk)
+            elif ctx.wino:
                 dx = conv3x3_wino(dy, weight, flip=True, residual=dxa)       # + the skip path's gradient in the epilogue
                 dxa = None
             elif ctx.p16 and _lib._precision == "bf16":

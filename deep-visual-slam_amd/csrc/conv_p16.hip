@@ -44,6 +44,10 @@ struct P16Params {
     const float* x2;
     const float* bias;
     int C1, up, reflect, org, Ho, Wo, act;
+    // thin kernel only: x is a gradient dY and aux the forward output Y of the same shape -- the staged value is dY * act'(Y)
+    // (dact: 1 ReLU, 2 ELU), i.e. the activation derivative of the layer whose data gradient this launch computes
+    const float* aux;
+    int dact;
 };
 
 // fp32 [N_w = Cout][3][3][Cin] -> bf16 [9][K / 16][N][16].  flip = 0: K = Cin, N = Cout, tap as stored; flip = 1 (data gradient):
@@ -297,6 +301,17 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_thin_kernel(P16Params p) {
         } else {
 #pragma unroll
             for (int j = 0; j < NLD; ++j) st[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], c * CKT * 4, 0));
+            if (p.dact) {                                                        // (no second source in this form)
+                const __amdgpu_buffer_rsrc_t ar =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aux), 0, (int)((size_t)p.B * Hs * Ws * C1 * 4), 0x00020000);
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, voff[j], c * CKT * 4, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        st[j][e] = p.dact == ACT_ELU ? fmaf(st[j][e], fminf(yv[e], 0.f), st[j][e]) : (yv[e] > 0.f ? st[j][e] : 0.f);
+                }
+            }
         }
         // the chunk's weights: rows (tap, k16 of the chunk, column) of 32 bytes -> sW in the same order
         f32x4 wv[WLD];
@@ -482,7 +497,8 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p)
 extern "C" {
 
 int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, const float* bias, float* y, int B, int H, int W, int C1, int C2,
-                         int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream) {
+                         int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, const float* y_out, int dact,
+                         void* stream) {
     DVS_REQUIRE(x && wpack && y && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0 && N > 0, "dvs_conv3x3_bf16_gen: bad argument");
     DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_bf16_gen: x2 and C2 go together");
     const bool big = C1 % CK == 0 && C2 % CK == 0 && N % 64 == 0;
@@ -495,9 +511,12 @@ int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, con
     DVS_REQUIRE(act == 0 || act == ACT_RELU || act == ACT_ELU, "dvs_conv3x3_bf16_gen: activation %d (0, 1 = ReLU, 2 = ELU)", act);
     const int K = C1 + C2;
     DVS_REQUIRE((double)B * Ho * Wo * (K > N ? K : N) * 4 < 2147483648.0, "dvs_conv3x3_bf16_gen: tensors must be smaller than 2 GiB");
+    DVS_REQUIRE(dact == 0 || ((dact == ACT_RELU || dact == ACT_ELU) && y_out && !big && C2 == 0 && !upsample),
+                "dvs_conv3x3_bf16_gen: the fused activation derivative (dact, y_out) exists in the thin kernel, one plain source");
     P16Params p{};
     p.x = x; p.x2 = x2; p.w = static_cast<const __bf16*>(wpack); p.bias = bias; p.y = y;
     p.B = B; p.H = H; p.W = W; p.K = K; p.N = N; p.C1 = C1; p.up = upsample; p.reflect = reflect; p.org = org; p.Ho = Ho; p.Wo = Wo; p.act = act;
+    p.aux = y_out; p.dact = dact;
     p.stat_split = B;
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, (hipStream_t)stream);
     prof.work(2.0 * B * H * W * (double)N * 9.0 * K);

@@ -223,10 +223,14 @@ int dvs_conv3x3_wino_fwd_slots(const float* x, const float* u, const float* bias
  *   operands (both k-strided, fetched with ds_read_b64_tr_b16), fp32 accumulation, float atomics into dw (about target_workgroups
  *   workgroups, 0 = default; a workgroup owns a 32 x 32 x 9 block and a range of patches).  Cin % 32 == 0, Cout % 32 == 0. */
 int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout, int target_workgroups, void* stream);
-/*   dvs_conv3x3_bf16_gen: the patch kernel behind the decoder's gathers -- arguments as dvs_conv3x3_wino_gen (x / x2 / C1 / C2 / Ho / Wo /
- *   org / upsample / reflect / act), wpack from dvs_conv3x3_bf16_pack over K = C1 + C2.  C1, C2, N multiples of 64. */
+/*   dvs_conv3x3_bf16_gen: the patch kernels behind the decoder's gathers -- arguments as dvs_conv3x3_wino_gen (x / x2 / C1 / C2 / Ho / Wo /
+ *   org / upsample / reflect / act), wpack from dvs_conv3x3_bf16_pack over K = C1 + C2 (its N padded to 32 columns).  C1, C2, N
+ *   multiples of 64: 64-channel chunks, 64 / 128 output channels per workgroup; otherwise multiples of 16: the thin kernel (32 output
+ *   channels per workgroup, the chunk's weights in LDS).  dact != 0 (thin kernel, one plain source): x is a gradient dY and y_out the
+ *   forward output of the same shape, the staged operand is dY * act'(y_out) (1 ReLU, 2 ELU). */
 int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, const float* bias, float* y, int B, int H, int W, int C1, int C2,
-                         int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, void* stream);
+                         int N, int Ho, int Wo, int org, int upsample, int reflect, int act, int as_dgrad, const float* y_out, int dact,
+                         void* stream);
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream);
 int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, float* y, float* stats, int stat_groups, int stat_slots, int B,
                          int H, int W, int K, int N, int as_dgrad, void* stream);
