@@ -75,6 +75,7 @@ _SIGNATURES = {
     "dvs_conv3x3_wino_fwd_slots": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 9 + [_vp]),
     "dvs_conv3x3_bf16_pack": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "dvs_conv3x3_bf16_wgrad": (C.c_int, [_vp, _vp, _vp] + [C.c_int] * 6 + [_vp]),
+    "dvs_conv3x3_bf16_wgrad_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [C.c_int] * 10 + [_vp]),
     "dvs_conv3x3_bf16_gen": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 13 + [_vp, C.c_int, _vp]),
     "dvs_conv3x3_bf16_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp] + [C.c_int] * 8 + [_vp]),
     "dvs_conv2d_pack_wt": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -388,6 +388,37 @@ def conv3x3_p16_wgrad(x, dy, weight_shape, dw_out=None, pooled=False):
     return None if dw_out is not None else dw
 
 
+def conv3x3_p16_wgrad_gen(x, x2, dy, weight_shape, dw_out=None, pooled=False, y_out=None, act=None, want_bias=False, db_out=None):
+    """Weight gradient of ReflectionPad2d(1) + [nearest 2x upsample of x (+ concat with x2)] + 3x3 with bf16 operands on the patch
+    kernel (arguments and results as conv3x3_wino_wgrad_gen)."""
+    x, dy = _nhwc(x), _nhwc(dy)
+    co, ci = weight_shape[:2]
+    up = x2 is not None
+    skip = _nhwc(x2) if isinstance(x2, torch.Tensor) else None
+    B, c1, hs, ws = x.shape
+    H, W = (2 * hs, 2 * ws) if up else (hs, ws)
+    c2 = skip.shape[1] if skip is not None else 0
+    if c1 + c2 != ci or tuple(dy.shape) != (B, co, H, W) or (skip is not None and tuple(skip.shape) != (B, c2, H, W)):
+        raise _lib.DvsError("conv3x3_p16_wgrad_gen: operands %s / %s / dy %s do not fit a %s weight at %dx%d"
+                            % (tuple(x.shape), None if skip is None else tuple(skip.shape), tuple(dy.shape), tuple(weight_shape), H, W))
+    dact = ACT[act]
+    if (want_bias or db_out is not None) and not dact:
+        raise _lib.DvsError("conv3x3_p16_wgrad_gen: the bias gradient rides on the activation-derivative path")
+    if dact and (y_out is None or tuple(y_out.shape) != tuple(dy.shape)):
+        raise _lib.DvsError("conv3x3_p16_wgrad_gen: the activation derivative needs the forward output")
+    if dw_out is not None:
+        if tuple(dw_out.shape) != tuple(weight_shape) or not dw_out.permute(0, 2, 3, 1).is_contiguous():
+            raise _lib.DvsError("conv3x3_p16_wgrad_gen: gradient sink must be a [Cout][kh][kw][Cin]-stored tensor of the weight's shape")
+        dw = dw_out
+    else:
+        dw = zeropool.zeros(tuple(weight_shape), dy.device, channels_last=True, pooled=pooled)
+    db = db_out if db_out is not None else (zeropool.zeros((co,), dy.device, pooled=pooled) if want_bias else None)
+    check(_lib.lib().dvs_conv3x3_bf16_wgrad_gen(x.data_ptr(), skip.data_ptr() if skip is not None else None, dy.data_ptr(),
+                                                _nhwc(y_out).data_ptr() if dact else None, dw.data_ptr(), ptr(db), B, H, W, c1, c2, co,
+                                                int(up), 1, dact, _P16_WGS, _lib.stream()), "dvs_conv3x3_bf16_wgrad_gen")
+    return (None if dw_out is not None else dw), (None if db_out is not None else db)
+
+
 STAT_SLOTS = int(os.environ.get("DVS_WINO_STAT_SLOTS", "16"))     # copies of the statistics table the Winograd forward spreads its atomics over
 
 
@@ -788,6 +819,13 @@ class _Conv2d(torch.autograd.Function):
                         and wino_dec_wgrad_eligible(weight.shape, x, x2)
                         and wino_dec_wgrad_pays(dy.shape[0], dy.shape[2], dy.shape[3], weight.shape[1], weight.shape[0]))
             p16_w = ctx.p16 and _lib._precision == "bf16" and not ctx.has_bias and not _lib.deterministic()
+            # bf16 mode: the decoder's layers with 32-channel blocks on the patch kernel's reflect / upsample / concat gather
+            c2w = x2.shape[1] if isinstance(x2, torch.Tensor) else 0
+            p16_gen_w = (_P16 and _lib._precision == "bf16" and not _lib.deterministic() and reflect and stride == 1 and pad == 1
+                         and not planar and scale is None and weight.shape[2] == 3 and weight.shape[3] == 3
+                         and act in (None, "elu", "relu") and (ACT[act] or not want_b) and weight.shape[0] % 32 == 0
+                         and x.shape[1] % 32 == 0 and c2w % 32 == 0 and x.shape[1] + c2w == weight.shape[1]
+                         and dy.numel() // dy.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
             if side is None:
                 if wsink is not None or bsink is not None:
                     gradsink.note(weight, gradsink.cur_stream())
@@ -796,6 +834,9 @@ class _Conv2d(torch.autograd.Function):
                     dw = conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
                 elif p16_w:
                     dw = conv3x3_p16_wgrad(x, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight))
+                elif p16_gen_w:
+                    dw, db = conv3x3_p16_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight), y_out=y,
+                                                   act=act, want_bias=want_b, db_out=bsink_w)
                 elif wino_gen:
                     dw, db = conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, pooled=_has_grad(weight), y_out=y,
                                                     act=act, want_bias=want_b, db_out=bsink_w)
@@ -820,6 +861,8 @@ class _Conv2d(torch.autograd.Function):
                         conv3x3_wino_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
                     elif p16_w:
                         conv3x3_p16_wgrad(x, dy, tuple(weight.shape), dw_out=wsink)
+                    elif p16_gen_w:
+                        conv3x3_p16_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, y_out=y, act=act, db_out=bsink_w)
                     elif wino_gen:
                         conv3x3_wino_wgrad_gen(x, x2, dy, tuple(weight.shape), dw_out=wsink, y_out=y, act=act, db_out=bsink_w)
                     else:

@@ -377,6 +377,13 @@ struct P16WgradParams {
     float* dw;               // [Cout][3][3][Cin]
     int B, H, W, Cin, Cout;
     int tiles_x, tiles_y, npatch, nblk_ci, nblocks, nsplit, per_split;
+    // GEN (the decoder's layers): the convolution's input is cat(x [, x2]) behind ReflectionPad2d(1) (reflect) / a nearest 2x upsample
+    // of x (up: x is [B][H/2][W/2][C1]); C1 % 32 == 0.  dact != 0: dy is multiplied by act'(y_out) as it is staged (1 ReLU, 2 ELU) and
+    // dbias (optional) += its column sums, taken by the workgroups of input-channel block 0.
+    const float* x2;
+    const float* y_out;
+    float* dbias;
+    int C1, up, reflect, dact;
 };
 
 using s16x4 = __attribute__((ext_vector_type(4))) short;
@@ -388,7 +395,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const __bf16* lo, const __bf16* hi) {
     return __builtin_bit_cast(bf16x8, s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 
-__global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p) {
+template <bool GEN>
+__global__ __launch_bounds__(NT, 2) void conv3x3_p16_wgrad_kernel(P16WgradParams p) {      // (two waves per SIMD: 144 accumulators + <= 112)
     constexpr int NDY = PH * PW, DY_IT = NDY * (WB / 4) / NT, X_IT = (NPIX * (WB / 4) + NT - 1) / NT;      // 4 and 6 staging items per thread
     __shared__ __attribute__((aligned(16))) __bf16 sD[2][NDY * WB];
     __shared__ __attribute__((aligned(16))) __bf16 sX[2][NPIX * WB];
@@ -412,11 +420,20 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p)
     const int co0 = (block / p.nblk_ci) * WB, ci0 = (block % p.nblk_ci) * WB;
     const int t_begin = split * p.per_split, t_end = min(p.npatch, t_begin + p.per_split);
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((size_t)p.B * H * W * Cin * 4), 0x00020000);
+    // my input-channel block lives in ONE source: x (C1 channels, half resolution when `up`) or the skip x2 (Cin - C1 channels)
+    const bool second = GEN && ci0 >= p.C1;
+    const int Cs = GEN ? (second ? Cin - p.C1 : p.C1) : Cin, cs0 = second ? ci0 - p.C1 : ci0;
+    const bool ups = GEN && p.up && !second;
+    const int Hs = ups ? H >> 1 : H, Ws = ups ? W >> 1 : W;
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(second ? p.x2 : p.x), 0, (int)((size_t)p.B * Hs * Ws * Cs * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)((size_t)p.B * H * W * Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((GEN && p.dact) ? p.y_out : p.dy), 0,
+                                                                         (GEN && p.dact) ? (int)((size_t)p.B * H * W * Cout * 4) : 0, 0x00020000);
     const int c4 = tid & 7, pix0 = tid >> 3;                                     // item j: pixel pix0 + 32 j, channels 4 c4 ..
     const int tpi = p.tiles_x * p.tiles_y;
-    f32x4 sd[DY_IT], sx[X_IT];
+    f32x4 sd[DY_IT], sx[X_IT], bsum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = GEN && p.dbias != nullptr && ci0 == 0;
     auto load_patch = [&](int t) __attribute__((always_inline)) {
         const int b = t / tpi, trem = t - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
         const int y0 = ty * PH, x0 = tx * PW;
@@ -425,19 +442,33 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p)
             const int pix = pix0 + 32 * j, gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
             const unsigned off = (gy < H && gx < W) ? (unsigned)((((b * H + gy) * W + gx) * Cout + co0 + 4 * c4) * 4) : OOB;
             sd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
+            if (GEN && p.dact) {
+                const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, off, 0, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sd[j][e] = p.dact == ACT_ELU ? fmaf(sd[j][e], fminf(yv[e], 0.f), sd[j][e]) : (yv[e] > 0.f ? sd[j][e] : 0.f);
+            }
         }
 #pragma unroll
         for (int j = 0; j < X_IT; ++j) {
             const int pix = pix0 + 32 * j, iy = pix / IW, ix = pix - iy * IW;
-            const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            if (GEN && p.reflect) {                        // ReflectionPad2d(1): -1 -> 1, H -> H - 2
+                gy = gy < 0 ? -gy : gy >= H ? 2 * H - 2 - gy : gy;
+                gx = gx < 0 ? -gx : gx >= W ? 2 * W - 2 - gx : gx;
+            }
             const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const unsigned off = ok ? (unsigned)((((b * H + gy) * W + gx) * Cin + ci0 + 4 * c4) * 4) : OOB;
+            const int sy = ups ? gy >> 1 : gy, sxx = ups ? gx >> 1 : gx;
+            const unsigned off = ok ? (unsigned)((((b * Hs + sy) * Ws + sxx) * Cs + cs0 + 4 * c4) * 4) : OOB;
             sx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
         }
     };
     auto store_patch = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < DY_IT; ++j) *reinterpret_cast<bf16x4*>(&sD[buf][(pix0 + 32 * j) * WB + 4 * c4]) = to_bf16(sd[j]);
+        for (int j = 0; j < DY_IT; ++j) {
+            *reinterpret_cast<bf16x4*>(&sD[buf][(pix0 + 32 * j) * WB + 4 * c4]) = to_bf16(sd[j]);
+            if (do_bias) bsum += sd[j];                  // (pixels outside the image were loaded as zeros)
+        }
 #pragma unroll
         for (int j = 0; j < X_IT; ++j)
             if (pix0 + 32 * j < NPIX) *reinterpret_cast<bf16x4*>(&sX[buf][(pix0 + 32 * j) * WB + 4 * c4]) = to_bf16(sx[j]);
@@ -489,6 +520,16 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_wgrad_kernel(P16WgradParams p)
             const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * h;
             atomicAdd(p.dw + ((size_t)co * 9 + tap) * Cin + ci0 + r, v);
         }
+    }
+    if (do_bias) {                                       // column sums of the staged dY: threads with equal c4 hold the same four channels
+        __syncthreads();
+        float* sB = &sR[0][0][0];
+        if (tid < WB) sB[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&sB[4 * c4 + e], bsum[e]);
+        __syncthreads();
+        if (tid < WB) atomicAdd(p.dbias + co0 + tid, sB[tid]);
     }
 }
 
@@ -552,8 +593,39 @@ int dvs_conv3x3_bf16_wgrad(const float* x, const float* dy, float* dw, int B, in
     const int grid = p.nsplit >= 8 ? p.nblocks * ((p.nsplit + 7) / 8) * 8 : p.nblocks * p.nsplit;
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, (hipStream_t)stream);
     prof.work(2.0 * B * H * W * (double)Cout * 9.0 * Cin);
-    hipLaunchKernelGGL(conv3x3_p16_wgrad_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv3x3_p16_wgrad_kernel<false>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
     return dvs::check_launch("dvs_conv3x3_bf16_wgrad");
+}
+
+int dvs_conv3x3_bf16_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
+                               int C1, int C2, int Cout, int upsample, int reflect, int dact, int target_workgroups, void* stream) {
+    DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dvs_conv3x3_bf16_wgrad_gen: bad argument");
+    DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_bf16_wgrad_gen: x2 and C2 go together");
+    DVS_REQUIRE(C1 % WB == 0 && C2 % WB == 0 && Cout % WB == 0 && Cout > 0, "dvs_conv3x3_bf16_wgrad_gen: channel counts must be multiples of 32 (got %d, %d, %d)",
+                C1, C2, Cout);
+    DVS_REQUIRE(!reflect || (H >= 2 && W >= 2), "dvs_conv3x3_bf16_wgrad_gen: ReflectionPad2d(1) needs H, W >= 2");
+    DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_bf16_wgrad_gen: upsampled input has even H, W");
+    DVS_REQUIRE(dact == 0 || ((dact == ACT_RELU || dact == ACT_ELU) && y_out), "dvs_conv3x3_bf16_wgrad_gen: dact 1 (ReLU) / 2 (ELU) needs the forward output");
+    DVS_REQUIRE(dbias == nullptr || dact != 0, "dvs_conv3x3_bf16_wgrad_gen: the bias gradient rides on the activation-derivative path");
+    const int Cin = C1 + C2;
+    DVS_REQUIRE((double)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483648.0, "dvs_conv3x3_bf16_wgrad_gen: tensors must be smaller than 2 GiB");
+    P16WgradParams p{};
+    p.x = x; p.x2 = x2; p.dy = dy; p.y_out = y_out; p.dw = dw; p.dbias = dbias;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.C1 = C1; p.up = upsample; p.reflect = reflect; p.dact = dact;
+    p.tiles_x = (W + PW - 1) / PW; p.tiles_y = (H + PH - 1) / PH;
+    p.npatch = B * p.tiles_x * p.tiles_y;
+    p.nblk_ci = Cin / WB;
+    p.nblocks = (Cout / WB) * p.nblk_ci;
+    const int target = target_workgroups > 0 ? target_workgroups : 512;
+    int nsplit = (target + p.nblocks - 1) / p.nblocks;
+    nsplit = nsplit < 1 ? 1 : (nsplit > p.npatch ? p.npatch : nsplit);
+    p.per_split = (p.npatch + nsplit - 1) / nsplit;
+    p.nsplit = (p.npatch + p.per_split - 1) / p.per_split;
+    const int grid = p.nsplit >= 8 ? p.nblocks * ((p.nsplit + 7) / 8) * 8 : p.nblocks * p.nsplit;
+    dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, (hipStream_t)stream);
+    prof.work(2.0 * B * H * W * (double)Cout * 9.0 * Cin);
+    hipLaunchKernelGGL(conv3x3_p16_wgrad_kernel<true>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, p);
+    return dvs::check_launch("dvs_conv3x3_bf16_wgrad_gen");
 }
 
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream) {
