@@ -823,8 +823,9 @@ class _Conv2d(torch.autograd.Function):
             c2w = x2.shape[1] if isinstance(x2, torch.Tensor) else 0
             p16_gen_w = (_P16 and _lib._precision == "bf16" and not _lib.deterministic() and reflect and stride == 1 and pad == 1
                          and not planar and scale is None and weight.shape[2] == 3 and weight.shape[3] == 3
-                         and act in (None, "elu", "relu") and (ACT[act] or not want_b) and weight.shape[0] % 32 == 0
-                         and x.shape[1] % 32 == 0 and c2w % 32 == 0 and x.shape[1] + c2w == weight.shape[1]
+                         and act in (None, "elu", "relu") and (ACT[act] or not want_b) and weight.shape[0] % 16 == 0
+                         and x.shape[1] % 16 == 0 and c2w % 16 == 0 and (c2w == 0 or x.shape[1] % 32 == 0)
+                         and x.shape[1] + c2w == weight.shape[1]
                          and dy.numel() // dy.shape[1] * max(weight.shape[0], weight.shape[1]) * 4 < 2 ** 31)
             if side is None:
                 if wsink is not None or bsink is not None:

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_p16_wgrad_kernel(P16WgradParams
 #pragma unroll
         for (int j = 0; j < DY_IT; ++j) {
             const int pix = pix0 + 32 * j, gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-            const unsigned off = (gy < H && gx < W) ? (unsigned)((((b * H + gy) * W + gx) * Cout + co0 + 4 * c4) * 4) : OOB;
+            const unsigned off = (gy < H && gx < W && co0 + 4 * c4 < Cout) ? (unsigned)((((b * H + gy) * W + gx) * Cout + co0 + 4 * c4) * 4) : OOB;
             sd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
             if (GEN && p.dact) {
                 const f32x4 yv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, off, 0, 0));
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_p16_wgrad_kernel(P16WgradParams
                 gy = gy < 0 ? -gy : gy >= H ? 2 * H - 2 - gy : gy;
                 gx = gx < 0 ? -gx : gx >= W ? 2 * W - 2 - gx : gx;
             }
-            const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const bool ok = pix < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && cs0 + 4 * c4 < Cs;
             const int sy = ups ? gy >> 1 : gy, sxx = ups ? gx >> 1 : gx;
             const unsigned off = ok ? (unsigned)((((b * Hs + sy) * Ws + sxx) * Cs + cs0 + 4 * c4) * 4) : OOB;
             sx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_p16_wgrad_kernel(P16WgradParams
             const int i = 4 * wave + k;                                          // wave w adds registers 4 w .. 4 w + 3 of the four waves
             const float v = sR[0][i][lane] + sR[1][i][lane] + sR[2][i][lane] + sR[3][i][lane];
             const int co = co0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            atomicAdd(p.dw + ((size_t)co * 9 + tap) * Cin + ci0 + r, v);
+            if (co < Cout && ci0 + r < Cin) atomicAdd(p.dw + ((size_t)co * 9 + tap) * Cin + ci0 + r, v);      // (16-channel layers: half a block)
         }
     }
     if (do_bias) {                                       // column sums of the staged dY: threads with equal c4 hold the same four channels
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_p16_wgrad_kernel(P16WgradParams
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(&sB[4 * c4 + e], bsum[e]);
         __syncthreads();
-        if (tid < WB) atomicAdd(p.dbias + co0 + tid, sB[tid]);
+        if (tid < WB && co0 + tid < Cout) atomicAdd(p.dbias + co0 + tid, sB[tid]);
     }
 }
 
@@ -601,8 +601,8 @@ int dvs_conv3x3_bf16_wgrad_gen(const float* x, const float* x2, const float* dy,
                                int C1, int C2, int Cout, int upsample, int reflect, int dact, int target_workgroups, void* stream) {
     DVS_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C1 > 0 && C2 >= 0, "dvs_conv3x3_bf16_wgrad_gen: bad argument");
     DVS_REQUIRE((C2 == 0) == (x2 == nullptr), "dvs_conv3x3_bf16_wgrad_gen: x2 and C2 go together");
-    DVS_REQUIRE(C1 % WB == 0 && C2 % WB == 0 && Cout % WB == 0 && Cout > 0, "dvs_conv3x3_bf16_wgrad_gen: channel counts must be multiples of 32 (got %d, %d, %d)",
-                C1, C2, Cout);
+    DVS_REQUIRE(C1 % 16 == 0 && C2 % 16 == 0 && Cout % 16 == 0 && Cout > 0 && (C2 == 0 || C1 % WB == 0),
+                "dvs_conv3x3_bf16_wgrad_gen: channel counts must be multiples of 16, C1 of 32 when there is a second source (got %d, %d, %d)", C1, C2, Cout);
     DVS_REQUIRE(!reflect || (H >= 2 && W >= 2), "dvs_conv3x3_bf16_wgrad_gen: ReflectionPad2d(1) needs H, W >= 2");
     DVS_REQUIRE(!upsample || ((H & 1) == 0 && (W & 1) == 0), "dvs_conv3x3_bf16_wgrad_gen: upsampled input has even H, W");
     DVS_REQUIRE(dact == 0 || ((dact == ACT_RELU || dact == ACT_ELU) && y_out), "dvs_conv3x3_bf16_wgrad_gen: dact 1 (ReLU) / 2 (ELU) needs the forward output");
@@ -614,8 +614,8 @@ int dvs_conv3x3_bf16_wgrad_gen(const float* x, const float* x2, const float* dy,
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.C1 = C1; p.up = upsample; p.reflect = reflect; p.dact = dact;
     p.tiles_x = (W + PW - 1) / PW; p.tiles_y = (H + PH - 1) / PH;
     p.npatch = B * p.tiles_x * p.tiles_y;
-    p.nblk_ci = Cin / WB;
-    p.nblocks = (Cout / WB) * p.nblk_ci;
+    p.nblk_ci = (Cin + WB - 1) / WB;
+    p.nblocks = ((Cout + WB - 1) / WB) * p.nblk_ci;
     const int target = target_workgroups > 0 ? target_workgroups : 512;
     int nsplit = (target + p.nblocks - 1) / p.nblocks;
     nsplit = nsplit < 1 ? 1 : (nsplit > p.npatch ? p.npatch : nsplit);

@@ -233,7 +233,7 @@ int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, con
                          void* stream);
 /*   dvs_conv3x3_bf16_wgrad_gen: the same behind the decoder's gathers (arguments as dvs_conv3x3_wino_wgrad_gen, + reflect): dw
  *   [Cout][3][3][C1+C2] += d/dw of conv3x3(pad(cat(x [, x2]))), dy optionally multiplied by act'(y_out) as it is staged (dact) with
- *   dbias += its column sums.  C1, C2, Cout multiples of 32. */
+ *   dbias += its column sums.  C1, C2, Cout multiples of 16 (C1 of 32 when there is a second source). */
 int dvs_conv3x3_bf16_wgrad_gen(const float* x, const float* x2, const float* dy, const float* y_out, float* dw, float* dbias, int B, int H, int W,
                                int C1, int C2, int Cout, int upsample, int reflect, int dact, int target_workgroups, void* stream);
 int dvs_conv3x3_bf16_pack(const float* w, void* out, int Cout, int Cin, int flip, void* stream);
