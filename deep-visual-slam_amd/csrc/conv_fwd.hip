@@ -516,6 +516,13 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
 template <int BM, int BN, int WM, int WN, int MODE, bool FOLD>
 void launch_cfg(const FwdParams& p0, hipStream_t st, int slot) {
     FwdParams p = p0;
+    if constexpr (MODE == IN_PLANAR) {
+        if (dvs::precision_bf16()) {            // the stems in the bf16 mode: the generic planar gather beside the bf16 matrix pipe
+            p.dbg_nobarrier = 0;
+            launch_buf<BM, BN, WM, WN, MODE, FOLD, 2, true>(p, st, slot);
+            return;
+        }
+    }
     if constexpr (!FOLD && MODE != IN_PLANAR) {
         // dvs_set_precision(1): the register-staged kernel with bf16 tiles (the LDS-DMA path cannot convert on the way)
         if (dvs::precision_bf16() && (p.s.Cin & 3) == 0) {
@@ -893,7 +900,9 @@ int dvs_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
-    if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE && !p.res) {
+    // (DVS_BF16_STEM=1: the stems on the generic planar kernel with bf16 tiles -- measured SLOWER than the fp32 stem kernels, 17.0 vs 16.2 ms per step)
+    static const bool stem16 = [] { const char* e = getenv("DVS_BF16_STEM"); return e && e[0] == '1'; }();
+    if (planar && stem_shape(s) && !p.t.in_relu && bias == nullptr && p.act == ACT_NONE && !p.res && !(stem16 && dvs::precision_bf16())) {
         dvs::ProfScope prof(dvs::SLOT_CONV_FWD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
         stem_fwd(x, w, y, p.stats, f && f->stat_groups == 2 ? 2 : 1, s, p.t.in_scale, p.t.in_shift, st);

@@ -682,6 +682,12 @@ void launch_cfg(WgradParams p, hipStream_t st, size_t* need = nullptr) {
     dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
     const double k_real = (MODE == IN_PLANAR) ? (double)p.s.Cin * p.s.kh * p.s.kw : (double)p.s.Ktot;
     prof.work(2.0 * M * p.s.Cout * k_real);
+    if constexpr (MODE == IN_PLANAR) {
+        if (dvs::precision_bf16()) {       // the stems in the bf16 mode
+            hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD, true>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
+            return;
+        }
+    }
     if constexpr (!FOLD && MODE != IN_PLANAR) {
         if (dvs::precision_bf16()) {       // bf16 tiles: the register-staged kernel (the LDS-DMA ones cannot convert on the way)
             hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM, WN, MODE, FOLD, true>), dim3(grid.x * grid.y * grid.z), dim3(NT), 0, st, p);
@@ -760,7 +766,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, float* dbias, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fold = p.t.in_scale != nullptr;
     if (need) *need = 0;
-    if (planar && stem_shape(s) && dact == 0 && dbias == nullptr && !p.t.in_relu) {
+    // (DVS_BF16_STEM=1: the stems on the generic planar kernel with bf16 tiles -- measured SLOWER than the fp32 stem kernels, 17.0 vs 16.2 ms per step)
+    static const bool stem16 = [] { const char* e = getenv("DVS_BF16_STEM"); return e && e[0] == '1'; }();
+    if (planar && stem_shape(s) && dact == 0 && dbias == nullptr && !p.t.in_relu && !(stem16 && dvs::precision_bf16())) {
         if (need) return DVS_OK;
         dvs::ProfScope prof(dvs::SLOT_CONV_WGRAD, st);
         prof.work(2.0 * s.B * s.Ho * s.Wo * s.Cout * (double)s.Cin * s.kh * s.kw);
