@@ -346,14 +346,19 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, fl
     n1 = r * s;
 }
 
+// A workgroup-uniform float that the vector ALU computed (divisions, int -> float conversions) lives in a VECTOR register for the
+// rest of the kernel unless told otherwise; in chain_bwd_kernel, which runs at its register limit, two dozen of them were spilled
+// to scratch in the prologue and re-read in every loop (+ 0.5 GB of HBM traffic per launch).  v_readfirstlane moves them to SGPRs.
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
 __device__ __forceinline__ Geo make_geo(const dvs_chain_cfg& c) {
     Geo g;
-    g.min_disp = 1.0f / c.max_depth;
-    g.disp_range = 1.0f / c.min_depth - 1.0f / c.max_depth;
-    g.wm1 = (float)(c.W - 1);
-    g.hm1 = (float)(c.H - 1);
-    g.inv_wm1 = 1.0f / g.wm1;
-    g.inv_hm1 = 1.0f / g.hm1;
+    g.min_disp = uni(1.0f / c.max_depth);
+    g.disp_range = uni(1.0f / c.min_depth - 1.0f / c.max_depth);
+    g.wm1 = uni((float)(c.W - 1));
+    g.hm1 = uni((float)(c.H - 1));
+    g.inv_wm1 = uni(1.0f / g.wm1);
+    g.inv_hm1 = uni(1.0f / g.hm1);
     g.H = c.H;
     g.W = c.W;
     return g;
@@ -664,12 +669,12 @@ __global__ __launch_bounds__(NTB, NTB == 512 ? 4 : BWD_WAVES) void chain_bwd_ker
     const dvs_chain_cfg& c = p.cfg;
     const int H = c.H, W = c.W, HW = H * W, S = c.num_scales;
     const int b = blockIdx.z, X0 = blockIdx.x * TW, Y0 = blockIdx.y * TH;
-    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int tid0 = threadIdx.x;
+    const int wave = tid0 >> 6, lane = tid0 & 63;
     const Geo geo = make_geo(c);
     constexpr int PLB = BH * BW, PLF = FH * FW;
     const int tile = blockIdx.y * p.tiles_x + blockIdx.x, ntiles = p.tiles_x * p.tiles_y;
-    const int X = X0 + tx, Yb = Y0 + PXB * ty;      // my strip: column X, rows Yb .. Yb+3
+    int tid = tid0;
 
     const float* tgt = p.io.target + (size_t)b * 3 * HW;
     for (int i = tid; i < PLB; i += NTB) {
@@ -690,28 +695,33 @@ __global__ __launch_bounds__(NTB, NTB == 512 ? 4 : BWD_WAVES) void chain_bwd_ker
     }
     __syncthreads();
 
-    const float w_pix = 1.0f / ((float)c.B * (float)HW);
-    const float cx = 1.0f / ((float)c.B * (float)H * (float)(W - 1));
-    const float cy = 1.0f / ((float)c.B * (float)(H - 1) * (float)W);
-    // ReflectionPad2d(1): the window of border pixel 0 (W-1) reads column 1 (W-2) twice
-    const float wxm = (X == 1) ? 2.f : 1.f, wxp = (X == W - 2) ? 2.f : 1.f;
-
-    // field strip owned by this thread: column fcol, rows frow0 .. frow0+5 of the 1-px-halo tile
-    const int fcol = tid % FW, frow0 = (tid / FW) * FR;
-    const bool field_thread = tid < FT;
-    const int fpx = X0 - 1 + fcol;
-
+    const float w_pix = uni(1.0f / ((float)c.B * (float)HW));
+    const float cx = uni(1.0f / ((float)c.B * (float)H * (float)(W - 1)));
+    const float cy = uni(1.0f / ((float)c.B * (float)(H - 1) * (float)W));
     const int s_lo = (q.g.scale_end > q.g.scale_begin) ? q.g.scale_begin : 0;
     const int s_hi = (q.g.scale_end > q.g.scale_begin) ? min(q.g.scale_end, S) : S;
 #pragma unroll 1
     for (int s = s_lo; s < s_hi; ++s) {
+        // Everything a lane derives from its thread index -- strip coordinates, LDS addresses with their constants folded in, the
+        // 64-bit output pointers -- is loop invariant, so the compiler hoists it all in front of this loop and, at the register
+        // limit, spills it there and reloads it in every phase (two dozen dwords, + 0.5 GB of scratch traffic per launch).  An opaque
+        // copy of the thread index per scale makes those few adds live where they are used.
+        asm volatile("" : "+v"(tid));
+        const int tx = tid & 63, ty = tid >> 6;
+        const int X = X0 + tx, Yb = Y0 + PXB * ty;      // my strip: column X, rows Yb .. Yb + PXB - 1
+        // ReflectionPad2d(1): the window of border pixel 0 (W-1) reads column 1 (W-2) twice
+        const float wxm = (X == 1) ? 2.f : 1.f, wxp = (X == W - 2) ? 2.f : 1.f;
+        // field strip owned by this thread: column fcol, rows frow0 .. frow0 + FR - 1 of the 1-px-halo tile
+        const int fcol = tid % FW, frow0 = (tid / FW) * FR;
+        const bool field_thread = tid < FT;
+        const int fpx = X0 - 1 + fcol;
         const int hs = c.hs[s], ws = c.ws[s];
         const bool same_res = (hs == H && ws == W);
         const float* dsp = p.io.disp[s] + (size_t)b * hs * ws;
-        const float ry = (float)hs / (float)H, rx = (float)ws / (float)W;
+        const float ry = uni((float)hs / (float)H), rx = uni((float)ws / (float)W);
         const float gl = q.g.d_losses[s];
-        const float w_ssim = gl * w_pix * c.ssim_ratio * (1.f / 3.f) * (-0.5f) * K9;
-        const float w_l1 = gl * w_pix * (1.f - c.ssim_ratio) * (1.f / 3.f);
+        const float w_ssim = uni(gl * w_pix * c.ssim_ratio * (1.f / 3.f) * (-0.5f) * K9);
+        const float w_l1 = uni(gl * w_pix * (1.f - c.ssim_ratio) * (1.f / 3.f));
         float gd[PXB];                        // d loss / d disp_up at my pixels
 #pragma unroll
         for (int k = 0; k < PXB; ++k) gd[k] = 0.f;

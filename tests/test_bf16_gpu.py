@@ -222,3 +222,48 @@ def test_training_step_bf16_against_fp32(gpu_device):
     assert abs(l16 - l32) / abs(l32) < 3e-2, (l16, l32)
     cos = float((g16.double() @ g32.double()) / (g16.double().norm() * g32.double().norm()))
     assert cos > 0.98, cos
+
+
+def test_trainer_opt_in_follows_autocast(gpu_device):
+    """Train.amp_bf16: the mode is armed while process_batch runs under torch.autocast (the use_amp branch of vo/train.py:177-185),
+    stays for the backward the caller runs after leaving autocast, and is dropped by the next call outside autocast."""
+    import sys
+    sys.path.insert(0, ".")
+    import bench
+    from torch.amp import GradScaler, autocast
+    from deep_visual_slam_amd import _lib, dp, synth
+    from deep_visual_slam_amd.depthnet import DepthNet
+    from deep_visual_slam_amd.learner_new import MonodepthTrainer
+    from deep_visual_slam_amd.posenet_single import PoseNet
+    try:
+        torch.manual_seed(0)
+        dn = DepthNet(18, pretrained=False).to(gpu_device).train()
+        pn = PoseNet(18, pretrained=False, num_input_images=2).to(gpu_device).train()
+        cfg = bench.train_config(2, 4)
+        cfg["Train"]["amp_bf16"] = True
+        flat = dp.FlatParams(dp.trainable_parameters(dn, pn))
+        opt = dp.FusedAdam(flat, lr=1e-4, params=list(dn.parameters()) + list(pn.parameters()))
+        tr = MonodepthTrainer(dn, pn, cfg, gpu_device)
+        sample = synth.throughput_sample(2, bench.H, bench.W, rank=0, device=gpu_device)
+        scaler = GradScaler()
+        assert _lib.precision() == "fp32"
+        with torch.no_grad():
+            _, l32 = tr.process_batch(dict(sample))            # not under autocast: fp32
+        assert _lib.precision() == "fp32"
+        tr._step = 0
+        opt.zero_grad(set_to_none=True)
+        with autocast(device_type="cuda"):
+            _, l16 = tr.process_batch(dict(sample))
+        assert _lib.precision() == "bf16"
+        scaler.scale(l16["loss"]).backward()                   # outside autocast, still the mode of this step
+        assert _lib.precision() == "bf16"
+        scaler.step(opt)
+        scaler.update()
+        a, b = float(l32["loss"]), float(l16["loss"])
+        assert a != b and abs(a - b) / abs(a) < 3e-2, (a, b)
+        assert all(torch.isfinite(p.grad).all() for p in dn.parameters() if p.grad is not None)
+        with torch.no_grad():
+            tr.process_batch(dict(sample))
+        assert _lib.precision() == "fp32"
+    finally:
+        _lib.set_precision("fp32")
