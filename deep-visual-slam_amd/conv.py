@@ -290,12 +290,16 @@ def p16_eligible(weight, stride, pad, reflect, act, x2, planar, scale):
 def _p16_weight(w, weight, flip):
     """bf16 [9][K/16][N][16] operand of the patch kernel (flip: the data gradient's), kept until the weight changes (same keying
     as _wino_weight)."""
+    # (torch's version counter AND the package's generation counter: dp.FusedAdam and the other raw-pointer writers change the
+    # weights behind torch's back and bump the latter -- nn_ops.bump_generation -- so a pack never outlives an optimiser step)
+    from . import nn_ops
+    stamp = (weight._version, nn_ops.generation())
     ent = _p16_packed.get(weight.data_ptr())
-    if not (ent is not None and ent[4]() is weight and ent[2] == weight._version and ent[3] == tuple(weight.shape)):
+    if not (ent is not None and ent[4]() is weight and ent[2] == stamp and ent[3] == tuple(weight.shape)):
         if len(_p16_packed) > 1024:
             for k in [k for k, e in _p16_packed.items() if e[4]() is None]:
                 del _p16_packed[k]
-        ent = [None, None, weight._version, tuple(weight.shape), weakref.ref(weight)]
+        ent = [None, None, stamp, tuple(weight.shape), weakref.ref(weight)]
         _p16_packed[weight.data_ptr()] = ent
     if ent[int(flip)] is None:
         k, n = (weight.shape[0], weight.shape[1]) if flip else (weight.shape[1], weight.shape[0])

@@ -267,3 +267,24 @@ def test_trainer_opt_in_follows_autocast(gpu_device):
         assert _lib.precision() == "fp32"
     finally:
         _lib.set_precision("fp32")
+
+
+def test_weight_pack_follows_the_fused_optimiser(gpu_device, bf16_mode):
+    """dp.FusedAdam updates the weights through a raw pointer (no torch version bump): the bf16 weight packs of the patch kernels
+    must not outlive that step."""
+    from deep_visual_slam_amd import conv as DC, dp
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, bias=False).to(gpu_device).to(memory_format=CL)
+    flat = dp.FlatParams([("w", conv.weight)])
+    opt = dp.FusedAdam(flat, lr=0.05)
+    w = conv.weight
+    x = torch.randn(2, 64, 16, 24, device=gpu_device).contiguous(memory_format=CL)
+    y0 = DC.conv3x3_p16(x, w)
+    assert relmax(y0, F.conv2d(r16(x), r16(w), None, 1, 1)) < 2e-5
+    w.grad.copy_(torch.randn_like(w))
+    opt.step()
+    torch.cuda.synchronize()
+    y1 = DC.conv3x3_p16(x, w)
+    y1_ref = F.conv2d(r16(x), r16(w), None, 1, 1)
+    assert relmax(y1, y1_ref) < 2e-5, relmax(y1, y1_ref)
+    assert relmax(y1, y0) > 1e-2              # the step did move the weights
