@@ -288,3 +288,44 @@ def test_weight_pack_follows_the_fused_optimiser(gpu_device, bf16_mode):
     y1_ref = F.conv2d(r16(x), r16(w), None, 1, 1)
     assert relmax(y1, y1_ref) < 2e-5, relmax(y1, y1_ref)
     assert relmax(y1, y0) > 1e-2              # the step did move the weights
+
+
+@pytest.mark.parametrize("cin,B,H,W", [(3, 2, 38, 50), (6, 4, 64, 132), (6, 2, 37, 259)])
+def test_stem_forward_bf16(gpu_device, bf16_mode, cin, B, H, W):
+    """conv1 (7x7, stride 2, pad 3, planar image with the input normalisation folded in; model/resnet_encoder.py:102-103,141) on the
+    bf16 stem kernel: operands = bf16(normalised image), bf16(weights); BatchNorm statistics from the fp32 results, two batch groups."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(7)
+    x = torch.rand(B, cin, H, W, device=gpu_device)
+    w = (torch.randn(64, cin, 7, 7, device=gpu_device) * 0.05)
+    sc = torch.full((cin,), 1 / 0.225, device=gpu_device)
+    sh = torch.full((cin,), -0.45 / 0.225, device=gpu_device)
+    stats = torch.zeros(2, 2, 64, device=gpu_device)
+    y = DC.conv2d_forward(x, w, None, 2, 3, False, None, in_scale=sc, in_shift=sh, nchw_planar=True, stats=stats, stat_groups=2)
+    xn = x * sc[None, :, None, None] + sh[None, :, None, None]
+    y_spec = F.conv2d(r16(xn), r16(w), None, 2, 3)
+    # (the kernel normalises with one fma, torch with a multiply and an add: a last-bit difference in fp32 that flips the bf16
+    # rounding of a few image operands -- 2^-9 of one product each)
+    assert y.shape == y_spec.shape and relmax(y, y_spec) < 2e-4, relmax(y, y_spec)
+    for g in range(2):
+        yy = y.double()[g * B // 2:(g + 1) * B // 2]
+        assert relmax(stats[g, 0], yy.sum((0, 2, 3))) < 1e-5
+        assert relmax(stats[g, 1], (yy ** 2).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("cin,B,H,W", [(3, 2, 38, 50), (6, 2, 64, 132), (6, 3, 37, 259)])
+def test_stem_weight_gradient_bf16(gpu_device, bf16_mode, cin, B, H, W):
+    """Weight gradient of conv1 on the bf16 stem kernel: bf16(dY) x bf16(normalised image), fp32 accumulation."""
+    from deep_visual_slam_amd import conv as DC
+    torch.manual_seed(8)
+    x = torch.rand(B, cin, H, W, device=gpu_device)
+    w = (torch.randn(64, cin, 7, 7, device=gpu_device) * 0.05).requires_grad_(True)
+    sc = torch.full((cin,), 1 / 0.225, device=gpu_device)
+    sh = torch.full((cin,), -0.45 / 0.225, device=gpu_device)
+    y = DC.conv2d(x, w, None, 2, 3, 0, None, planar_norm=(sc, sh))
+    cot = torch.randn_like(y)
+    (gw,) = torch.autograd.grad(y, [w], cot)
+    xn = x * sc[None, :, None, None] + sh[None, :, None, None]
+    wv = r16(w).requires_grad_(True)
+    (gw_spec,) = torch.autograd.grad(F.conv2d(r16(xn), wv, None, 2, 3), [wv], r16(cot))
+    assert gw.shape == gw_spec.shape and relmax(gw, gw_spec) < 2e-4, relmax(gw, gw_spec)
