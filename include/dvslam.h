@@ -58,8 +58,9 @@ int dvs_get_deterministic(void);
  * cores -- the reference's default precision and what every parity statement of this library is made for.  mode 1: bf16 operands
  * (rounded to nearest-even as they are staged into LDS), fp32 accumulation, fp32 tensors in HBM on both sides -- the counterpart
  * of the reference's `use_amp` branch (vo/train.py:44,177-185: torch.autocast + GradScaler around the same modules); forward,
- * data and weight gradient of dvs_conv2d_* take it, the Winograd / stem / thin / head kernels, BatchNorm, the loss chain and the
- * optimiser stay fp32.  Results then differ from mode 0 by bf16 operand rounding (2^-9 relative per product, averaging down over
+ * data and weight gradient of dvs_conv2d_* take it (the stems on bf16 kernels of their own), the dvs_conv3x3_bf16_* entry points
+ * below exist for it; the Winograd kernels (not used in the mode), the row-ring kernels of the 16-channel layers, the heads,
+ * BatchNorm, the loss chain and the optimiser stay fp32.  Results then differ from mode 0 by bf16 operand rounding (2^-9 relative per product, averaging down over
  * K): separately toleranced in tests/test_bf16_gpu.py, never the headline precision. */
 int dvs_set_precision(int mode);
 int dvs_get_precision(void);
