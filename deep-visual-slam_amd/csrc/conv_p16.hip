@@ -15,7 +15,17 @@
 //
 // Tensors stay fp32 in HBM on both sides; accumulation is fp32; the BatchNorm statistics are taken from the fp32 results as in
 // the fp32 kernels.  Data gradient: the same kernel over dY with the rotated / transposed pack (flip).
-// Replaces (in that mode) conv1 / conv2 of model/resnet_encoder.py's BasicBlocks (torchvision resnet18 layout).
+//
+// In this file:  conv3x3_p16_kernel<TN, GEN>   the patch kernel; GEN = behind the decoder's gathers (ReflectionPad2d, nearest 2x
+//                                              upsample, concat with the skip), + bias + ELU, and the full correlation of the
+//                                              padded-domain data gradient                       (dvs_conv3x3_bf16_fwd / _gen)
+//                conv3x3_p16_thin_kernel<CKT>  the 32- / 16-channel decoder levels: 32 output channels per workgroup, the chunk's
+//                                              weights in LDS, fused activation derivative        (dvs_conv3x3_bf16_gen)
+//                conv3x3_p16_wgrad_kernel<GEN> weight gradient, both operands through ds_read_b64_tr_b16
+//                                                                                                 (dvs_conv3x3_bf16_wgrad / _wgrad_gen)
+//                p16_pack_kernel               fp32 [Cout][3][3][Cin] -> bf16 [9][K / 16][N][16]  (dvs_conv3x3_bf16_pack)
+// Replaces (in that mode) conv1 / conv2 of model/resnet_encoder.py's BasicBlocks (torchvision resnet18 layout) and the
+// Conv3x3 / ConvBlock layers of model/layers.py:26-41,106-118 inside model/depth_decoder.py:52-62.
 #include "conv_common.h"
 
 #include <cstdint>
