@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
             for (int i = 0; i < 16; ++i) acc[tm][tn][i] = 0.f;
 
     const int nchunk = K / CK;
-    constexpr int STEPS = 9 * (CK / 16), DEPTH = 3;                             // 16-k steps per chunk; B operands fetched DEPTH steps ahead
+    constexpr int STEPS = 9 * (CK / 16), DEPTH = 3;                             // 16-k steps per chunk; B operands fetched DEPTH steps ahead (6 and 10: same times)
     load_chunk(0);
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
@@ -175,7 +175,11 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int tap = s / (CK / 16), c16 = s % (CK / 16);
+#ifdef P16_DBG_NOB            // timing experiment (tools/build_variant.py --flag=-DP16_DBG_NOB): the B operands of the first steps only
+            if (s + DEPTH < STEPS && s + DEPTH < 4) load_b(c, (s + DEPTH) / (CK / 16), (s + DEPTH) % (CK / 16), bq[(s + DEPTH) % (DEPTH + 1)]);
+#else
             if (s + DEPTH < STEPS) load_b(c, (s + DEPTH) / (CK / 16), (s + DEPTH) % (CK / 16), bq[(s + DEPTH) % (DEPTH + 1)]);
+#endif
             bf16x8 a[2];
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
