@@ -29,6 +29,7 @@
 #include "conv_common.h"
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 using namespace dvsconv;
@@ -82,17 +83,23 @@ __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__
     o[1] = hi;
 }
 
-template <int TN, bool GEN = false>      // TN: 32-column fragments per wave (the workgroup covers 64 TN output channels); GEN: see P16Params
+// TN: 32-column fragments per wave; GEN: see P16Params; WIDE: wave layout.  false: 2 x 2 waves, a wave owns 64 pixels x 32 TN channels
+// (the workgroup covers 64 TN output channels); true (TN = 1): 1 x 4 waves, a wave owns all 128 pixels x 32 channels (128 output
+// channels per workgroup) -- every B fragment is then fetched by ONE wave instead of two, half the weight bytes from L2, which is what
+// bounds the layers with many channel chunks
+template <int TN, bool GEN = false, bool WIDE = false>
 __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
+    constexpr int TM = WIDE ? 4 : 2, WNW = WIDE ? 4 : 2, BNW = 32 * WNW * TN;      // m-tiles per wave, waves along N, channels per workgroup
+    static_assert(!WIDE || TN == 1, "the 1 x 4 layout has one fragment column per wave");
     __shared__ __attribute__((aligned(16))) __bf16 sP[2][NPIX * LDP];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WNW, wn = wave % WNW;
     const int H = p.H, W = p.W, K = p.K, N = p.N;
-    const int nblk = N / (64 * TN);
+    const int nblk = N / BNW;
     const int bid = blockIdx.x, nb = bid % nblk, tile = bid / nblk;             // the channel blocks of a patch are neighbours (L2)
     const int tpi = p.tiles_x * p.tiles_y;
     const int b = tile / tpi, trem = tile - b * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int y0 = ty * PH, x0 = tx * PW, n0 = nb * 64 * TN;
+    const int y0 = ty * PH, x0 = tx * PW, n0 = nb * BNW;
     const int Ho = GEN ? p.Ho : H, Wo = GEN ? p.Wo : W, org = GEN ? p.org : 1;
     const int C1 = GEN ? p.C1 : K, C2 = K - C1;
     const int Hs = (GEN && p.up) ? H >> 1 : H, Ws = (GEN && p.up) ? W >> 1 : W;             // geometry of source x
@@ -139,9 +146,9 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
     };
 
     // ---- operands
-    int a_base[2];                                                              // my row of the two m-tiles (two patch rows each)
+    int a_base[TM];                                                             // my row of my m-tiles (two patch rows each)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) a_base[tm] = (((wm * 2 + tm) * 2 + (r >> 4)) * IW + (r & 15)) * LDP + 8 * h;
+    for (int tm = 0; tm < TM; ++tm) a_base[tm] = (((wm * TM + tm) * 2 + (r >> 4)) * IW + (r & 15)) * LDP + 8 * h;
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.w), 0, (int)((size_t)9 * K * N * 2), 0x00020000);
     const unsigned b_voff = (unsigned)(((n0 + wn * TN * 32 + r) * 16 + 8 * h) * 2);
     const int tap_stride = K * N * 2, k16_stride = N * 32;                      // bytes of the pack per tap, per 16-k block
@@ -152,9 +159,9 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
             bq[tn] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wr, b_voff, soff + tn * 1024, 0));
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -180,12 +187,12 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
 #else
             if (s + DEPTH < STEPS) load_b(c, (s + DEPTH) / (CK / 16), (s + DEPTH) % (CK / 16), bq[(s + DEPTH) % (DEPTH + 1)]);
 #endif
-            bf16x8 a[2];
+            bf16x8 a[TM];
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
                 a[tm] = *reinterpret_cast<const bf16x8*>(P + a_base[tm] + ((tap / 3) * IW + (tap % 3)) * LDP + 16 * c16);
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[tm], bq[s % (DEPTH + 1)][tn], acc[tm][tn], 0, 0, 0);
@@ -203,8 +210,8 @@ __global__ __launch_bounds__(NT) void conv3x3_p16_kernel(P16Params p) {
         const float bv = (GEN && p.bias) ? p.bias[co] : 0.f;
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int mt = wm * 2 + tm;
+        for (int tm = 0; tm < TM; ++tm) {
+            const int mt = wm * TM + tm;
             unsigned off[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -584,7 +591,9 @@ int dvs_conv3x3_bf16_gen(const float* x, const float* x2, const void* wpack, con
     }
     p.tiles_x = (Wo + PW - 1) / PW; p.tiles_y = (Ho + PH - 1) / PH;
     const int tiles = B * p.tiles_x * p.tiles_y;
-    if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    static const bool wide = [] { const char* e = getenv("DVS_BF16_WIDE"); return !(e && e[0] == '0'); }();
+    if (N % 128 == 0 && wide) hipLaunchKernelGGL((conv3x3_p16_kernel<1, true, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    else if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv3x3_p16_kernel<1, true>), dim3(tiles * (N / 64)), dim3(NT), 0, (hipStream_t)stream, p);
     return dvs::check_launch("dvs_conv3x3_bf16_gen");
 }
@@ -670,7 +679,9 @@ int dvs_conv3x3_bf16_fwd(const float* x, const void* wpack, const float* res, fl
     const int tiles = B * p.tiles_x * p.tiles_y;
     dvs::ProfScope prof(as_dgrad ? dvs::SLOT_CONV_DGRAD : dvs::SLOT_CONV_FWD, (hipStream_t)stream);
     prof.work(2.0 * B * H * W * (double)N * 9.0 * K);
-    if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    static const bool wide = [] { const char* e = getenv("DVS_BF16_WIDE"); return !(e && e[0] == '0'); }();
+    if (N % 128 == 0 && wide) hipLaunchKernelGGL((conv3x3_p16_kernel<1, false, true>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
+    else if (N % 128 == 0) hipLaunchKernelGGL((conv3x3_p16_kernel<2>), dim3(tiles * (N / 128)), dim3(NT), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((conv3x3_p16_kernel<1>), dim3(tiles * (N / 64)), dim3(NT), 0, (hipStream_t)stream, p);
     return dvs::check_launch("dvs_conv3x3_bf16_fwd");
 }
