@@ -391,6 +391,29 @@ def dav2_side(device, with_cpu, batches=(1, 8)):
             del gnet
         res["batches"]["batch_%d" % B] = entry
     res["value"] = res["batches"]["batch_%d" % batches[-1]]["value"]
+    # the same forward with the token GEMMs / DPT convolutions in the opt-in bf16 mode (include/dvslam.h dvs_set_precision; the
+    # attention kernel stays fp32): a separately labelled figure with the deviation of its output, never `value`
+    from deep_visual_slam_amd import _lib as _dvs_lib
+    if _dvs_lib.precision() == "fp32":
+        Bb = batches[-1]
+        xb = torch.randn(Bb, 3, 518, 518, device=device)
+        with torch.no_grad():
+            y32 = net(xb).float().clone()
+            try:
+                _dvs_lib.set_precision("bf16")
+                for _ in range(3):
+                    y16 = net(xb)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    net(xb)
+                torch.cuda.synchronize()
+                dtb = (time.perf_counter() - t0) / 20
+            finally:
+                _dvs_lib.set_precision("fp32")
+        res["bf16_mode"] = {"batch": Bb, "value": Bb / dtb, "ms_per_forward": dtb * 1e3,
+                            "dtype": "bf16 operands x fp32 accumulate in the token GEMMs / convolutions, fp32 attention, LayerNorm, GELU (opt-in mode)",
+                            "rel_max_diff_of_depth_vs_fp32": float((y16.float() - y32).abs().max() / y32.abs().max())}
     # the trainable path (autograd on): forward + backward of a scalar loss, batch 4
     Bt = 4
     net.train()

@@ -329,3 +329,23 @@ def test_stem_weight_gradient_bf16(gpu_device, bf16_mode, cin, B, H, W):
     wv = r16(w).requires_grad_(True)
     (gw_spec,) = torch.autograd.grad(F.conv2d(r16(xn), wv, None, 2, 3), [wv], r16(cot))
     assert gw.shape == gw_spec.shape and relmax(gw, gw_spec) < 2e-4, relmax(gw, gw_spec)
+
+
+def test_depth_anything_forward_bf16_against_fp32(gpu_device):
+    """configs[4] in the mode: the token GEMMs and the DPT head's convolutions take bf16 operands (attention, LayerNorm, GELU stay
+    fp32); the depth map of seeded random weights stays within 5e-3 of the fp32 one."""
+    from deep_visual_slam_amd import _lib
+    from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
+    torch.manual_seed(0)
+    net = DepthAnythingV2(encoder="vits", features=64, out_channels=[48, 96, 192, 384]).to(gpu_device).eval()
+    x = torch.rand(1, 3, 518, 518, device=gpu_device)
+    try:
+        with torch.no_grad():
+            y32 = net(x).float().clone()
+            _lib.set_precision("bf16")
+            y16 = net(x).float()
+    finally:
+        _lib.set_precision("fp32")
+    assert torch.isfinite(y16).all()
+    d = relmax(y16, y32)
+    assert 0.0 < d < 5e-3, d
