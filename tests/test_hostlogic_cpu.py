@@ -281,3 +281,39 @@ def test_packed_weights_release_only_their_own_entries():
     finally:
         DC._prepacked.pop(4096, None)
         DC._wino_packed.pop(4096, None)
+
+
+def test_stream_override_is_scoped_and_nests():
+    """_lib.on_stream hands the dvs_* calls another stream without switching torch's current stream: the handle is visible inside
+    the block only, nests, and is restored when the block raises."""
+    from deep_visual_slam_amd import _lib
+
+    class S:
+        def __init__(self, h):
+            self.cuda_stream = h
+
+    assert getattr(_lib._stream_tls, "override", None) is None
+    with _lib.on_stream(S(111)):
+        assert _lib.stream() == 111
+        with _lib.on_stream(S(222)):
+            assert _lib.stream() == 222
+        assert _lib.stream() == 111
+    assert getattr(_lib._stream_tls, "override", None) is None
+    try:
+        with _lib.on_stream(S(333)):
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert getattr(_lib._stream_tls, "override", None) is None
+
+
+def test_bf16_kernels_are_opt_in():
+    """The patch kernels of the bf16 mode are only ever chosen while the mode is on; the default precision is fp32."""
+    import torch
+    from deep_visual_slam_amd import _lib, conv
+    assert _lib.precision() == "fp32"
+    w = torch.zeros(64, 64, 3, 3)
+    x = torch.zeros(1, 64, 8, 8)
+    assert not conv.p16_eligible(w, 1, 1, False, None, None, False, None)
+    assert not conv.p16_dec_eligible(w, 1, 1, True, "elu", x, None, False, None)
+    assert conv._wino_on() == conv._WINO
