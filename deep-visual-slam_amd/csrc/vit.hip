@@ -193,6 +193,173 @@ __global__ __launch_bounds__(NT, 2) void attention_fwd_kernel(AttnParams p) {
 }
 
 
+// bf16 mode (dvs_set_precision(1)), inference forward (no log-sum-exp kept): the same kernel with both products on
+// v_mfma_f32_32x32x16_bf16 -- 8 matrix instructions per 32 x 32 tile instead of 64.  The loads are the fp32 kernel's; the operands
+// are rounded to bf16 in registers.  The second product uses the score tile as an operand in place (guide: an accumulator tile as the
+// next MFMA's operand): registers 8 s .. 8 s + 7 are the 16-key step s, whose k order is 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the
+// V^T operand is assembled in that same order from the loads the fp32 kernel already makes.  Softmax stays fp32.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+__device__ __forceinline__ bf16x8 pack8(f32x4 a, f32x4 b) {
+    return bf16x8{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__global__ __launch_bounds__(NT, 2) void attention_fwd_bf16_kernel(AttnParams p) {
+    __shared__ float sO[4][HD][QT + 1];        // per wave: O^T (dims x queries); +1: conflict-free transposed read
+    __shared__ float sM[4][QT], sL[4][QT];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // (scalar: the per-tile buffer resources derive from it)
+    const int q0 = blockIdx.x * QT, head = blockIdx.y, b = blockIdx.z;
+    const int N = p.N, C = p.heads * HD;
+    const size_t row = (size_t)3 * C;                                   // floats between consecutive tokens
+    const float* base = p.qkv + (size_t)b * N * row + (size_t)head * HD;
+    const float* Q = base, * K = base + C, * V = base + 2 * C;
+
+    // B operand of 16-dim step s: my query (column r), dims 16 s + 8 h .. + 7, pre-scaled, rounded to bf16
+    bf16x8 qh[4];
+    {
+        const int qi = min(q0 + r, N - 1);
+        const float* qp = Q + (size_t)qi * row;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(qp + 16 * s4 + 8 * h) * p.scale;
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(qp + 16 * s4 + 8 * h + 4) * p.scale;
+            qh[s4] = pack8(t0, t1);
+        }
+    }
+    f32x16 o0 = {0.f}, o1 = {0.f};             // O^T tiles: dims 0..31 and 32..63 x my query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (N + KT - 1) / KT;
+    // K / V through buffer resources that end with this image's last token: a key row past N reads zeros from the range check (its
+    // score is masked below, its V row multiplies p = 0), and a lane's 8 + 32 offsets are loop invariant -- the tile moves the
+    // resource's base.  (Round 2 clamped and multiplied every row index per load: ~160 vector instructions of address arithmetic per tile
+    // beside 64 fp32 MFMAs that run on the same vector pipe.)
+    const unsigned rowb = (unsigned)row * 4u, kvbytes = (unsigned)((size_t)N * row * 4 - (size_t)(C + head * HD) * 4);
+    unsigned koff[8], voff[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) koff[j] = (unsigned)r * rowb + (unsigned)(16 * (j >> 1) + 8 * h + 4 * (j & 1)) * 4u;      // step j >> 1, half j & 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            voff[0][j][u] = (unsigned)(8 * j + 4 * h + u) * rowb + (unsigned)r * 4u;
+            voff[1][j][u] = voff[0][j][u] + 128u;
+        }
+    for (int t = wave; t < ntiles; t += 4) {
+        const int k0 = t * KT;
+        // the tile's resources start at its first key row (scalar arithmetic); the range check looks at the voffset alone
+        const unsigned tb = (unsigned)k0 * rowb;
+        const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(K)) + tb, 0, (int)(kvbytes - tb), 0x00020000);
+        const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(V)) + tb, 0, (int)(kvbytes - (unsigned)C * 4u - tb), 0x00020000);
+        // ---- S^T = K Q^T : A operand of step s = key row k0 + r, dims 16 s + 8 h .. + 7 (loads 2 s and 2 s + 1)
+        f32x4 kv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(kr, koff[j], 0, 0));
+        // V^T operand: A[m = dim][k = key]: lane (r, h) of step j needs V[k0 + 8 j + 4 h + u][32 dt + r], u = 0..3
+        float vv[2][4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vv[0][j][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vr, voff[0][j][u], 0, 0));
+                vv[1][j][u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vr, voff[1][j][u], 0, 0));
+            }
+        }
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(kv[2 * s4], kv[2 * s4 + 1]), qh[s4], s, 0, 0, 0);
+        // s[i]: key k0 + (i & 3) + 8 (i >> 2) + 4 h, query q0 + r.  Keys beyond N do not exist.
+        if (k0 + KT > N) {                                     // (wave-uniform: only the last tile has such keys)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                s[i] = key < N ? s[i] : -INFINITY;
+            }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);                 // finite: every tile holds at least one real key
+        const float alpha = __expf(m_run - m_new);              // exp(-inf) = 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            s[i] = __expf(s[i] - m_new);
+            psum += s[i];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o0[i] *= alpha;
+            o1[i] *= alpha;
+        }
+        // ---- O^T += V^T P^T in two 16-key steps: element jj of lane half h is key 16 s2 + 8 (jj >> 2) + 4 h + (jj & 3) in BOTH operands --
+        // P^T from registers 8 s2 .. 8 s2 + 7 of the score tile, V^T from the loads (j = 2 s2 + (jj >> 2), u = jj & 3) above
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 ph = bf16x8{(__bf16)s[8 * s2], (__bf16)s[8 * s2 + 1], (__bf16)s[8 * s2 + 2], (__bf16)s[8 * s2 + 3],
+                                     (__bf16)s[8 * s2 + 4], (__bf16)s[8 * s2 + 5], (__bf16)s[8 * s2 + 6], (__bf16)s[8 * s2 + 7]};
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vh = bf16x8{(__bf16)vv[dt][2 * s2][0], (__bf16)vv[dt][2 * s2][1], (__bf16)vv[dt][2 * s2][2], (__bf16)vv[dt][2 * s2][3],
+                                         (__bf16)vv[dt][2 * s2 + 1][0], (__bf16)vv[dt][2 * s2 + 1][1], (__bf16)vv[dt][2 * s2 + 1][2],
+                                         (__bf16)vv[dt][2 * s2 + 1][3]};
+                if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o0, 0, 0, 0);
+                else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o1, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- merge the four waves' partial results: o[i] = O^T[dim = (i & 3) + 8 (i >> 2) + 4 h (+32)][query r]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int d = (i & 3) + 8 * (i >> 2) + 4 * h;
+        sO[wave][d][r] = o0[i];
+        sO[wave][32 + d][r] = o1[i];
+    }
+    if (h == 0) {
+        sM[wave][r] = m_run;
+        sL[wave][r] = l_run;
+    }
+    __syncthreads();
+    // thread -> (query = tid >> 3, 8 consecutive dims): a token's 64 output floats are one 256-byte segment
+    {
+        const int q = tid >> 3, d0 = (tid & 7) * 8;
+        const float m = fmaxf(fmaxf(sM[0][q], sM[1][q]), fmaxf(sM[2][q], sM[3][q]));
+        float w[4], l = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            w[v] = __expf(sM[v][q] - m);                       // a wave that saw no tile has m = -inf, l = 0: weight 0
+            l += w[v] * sL[v][q];
+        }
+        const float inv = 1.f / l;
+        if (p.lse && d0 == 0 && q0 + q < N) p.lse[((size_t)b * p.heads + head) * N + q0 + q] = m + __logf(l);
+        if (q0 + q < N) {
+            float* op = p.out + ((size_t)b * N + q0 + q) * C + (size_t)head * HD + d0;
+            float res[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc += w[v] * sO[v][d0 + e][q];
+                res[e] = acc * inv;
+            }
+            *reinterpret_cast<f32x4*>(op) = f32x4{res[0], res[1], res[2], res[3]};
+            *reinterpret_cast<f32x4*>(op + 4) = f32x4{res[4], res[5], res[6], res[7]};
+        }
+    }
+}
+
+
+
 // ---- attention backward -------------------------------------------------------------------------------------------------
 // With P = exp(S - lse), D_q = sum_d dO[q][d] O[q][d]:   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - D),
 // dQ = scale dS K,   dK = scale dS^T Q.   Two kernels in the forward's register layout, each recomputing S and dP for its
@@ -803,7 +970,10 @@ int dvs_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, in
     {
         dvs::ProfScope prof(dvs::SLOT_ATTN, st);
         prof.work(4.0 * B * heads * (double)N * N * HD);      // q k^T and p v: 2 N^2 d flops each
-        hipLaunchKernelGGL(attention_fwd_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
+        // bf16 mode: only where no log-sum-exp is kept (inference) -- the backward kernels recompute the scores in fp32
+        if (dvs::precision_bf16() && lse == nullptr)
+            hipLaunchKernelGGL(attention_fwd_bf16_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
+        else hipLaunchKernelGGL(attention_fwd_kernel, dim3((N + QT - 1) / QT, heads, B), dim3(NT), 0, st, p);
     }
     return dvs::check_launch("dvs_attention_fwd");
 }

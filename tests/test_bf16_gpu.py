@@ -331,9 +331,32 @@ def test_stem_weight_gradient_bf16(gpu_device, bf16_mode, cin, B, H, W):
     assert gw.shape == gw_spec.shape and relmax(gw, gw_spec) < 2e-4, relmax(gw, gw_spec)
 
 
+@pytest.mark.parametrize("B,N,heads", [(1, 1370, 6), (2, 49, 6), (3, 33, 2)])
+def test_attention_forward_bf16(gpu_device, B, N, heads):
+    """Inference attention in the mode: both products on bf16 MFMA (scaled q, k, the probabilities and v rounded to bf16, softmax and
+    accumulation fp32).  Checked against softmax(q k^T / 8) v in fp32 at 1e-2 of the output max, and it must differ from the fp32
+    kernel (the mode is really taken).  The training forward (log-sum-exp kept) stays fp32 -- test_dav2_gpu covers it."""
+    from deep_visual_slam_amd import _lib
+    from deep_visual_slam_amd.depth_anything_v2 import attention
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3, heads, 64, generator=g) * 1.5
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    ref = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B * N, heads * 64)
+    dev = qkv.reshape(B * N, -1).to(gpu_device)
+    y32 = attention(dev, B, N, heads, 64).clone()
+    try:
+        _lib.set_precision("bf16")
+        y16 = attention(dev, B, N, heads, 64)
+    finally:
+        _lib.set_precision("fp32")
+    assert relmax(y16.cpu(), ref) < 1e-2, relmax(y16.cpu(), ref)
+    assert relmax(y16, y32) > 0.0
+
+
 def test_depth_anything_forward_bf16_against_fp32(gpu_device):
-    """configs[4] in the mode: the token GEMMs and the DPT head's convolutions take bf16 operands (attention, LayerNorm, GELU stay
-    fp32); the depth map of seeded random weights stays within 5e-3 of the fp32 one."""
+    """configs[4] in the mode: the token GEMMs, the attention products and the DPT head's convolutions take bf16 operands (softmax,
+    LayerNorm, GELU stay fp32); the depth map of seeded random weights stays within 5e-3 of the fp32 one."""
     from deep_visual_slam_amd import _lib
     from deep_visual_slam_amd.depth_anything_v2 import DepthAnythingV2
     torch.manual_seed(0)
