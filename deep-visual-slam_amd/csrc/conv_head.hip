@@ -435,6 +435,187 @@ __global__ __launch_bounds__(HNT) void head_wgrad_rows_kernel(HeadParams p) {
         atomicAdd(p.dbias + threadIdx.x, sb[threadIdx.x] + sb[COUT + threadIdx.x] + sb[2 * COUT + threadIdx.x] + sb[3 * COUT + threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Input-indexed weight gradient of the one-channel 3x3 heads (round 3).  The row form above is indexed by the OUTPUT pixel: nine
+// 16-byte loads per lane and pixel, every x row fetched by three workgroups (three L2s): 274 MB of HBM reads per launch for 90 MB of
+// tensors, 105 us.  Re-indexed by the INPUT pixel,
+//     dw[ky][kx][ci] = sum over (iy, ix) of x(iy, ix, ci) * g(iy - ky + 1, ix - kx + 1),      g = dY * act'(Y), zero outside the image,
+// x is read exactly once (one coalesced 1 KB run per wave and row) and what a lane gathers is the 3x3 window of the ONE-channel g
+// -- dwords that stay in L1.  A wave owns 64 / (Cin/4) columns and walks a run of rows: the window slides in registers, one new row of
+// three g values per step.  ReflectionPad2d(1) folds into the window: output row 0 reads input row 1 through ky = 0, so at iy = 1
+// tap ky = 0 also takes what ky = 2 takes (g row 0), at iy = H - 2 tap ky = 2 takes g row H - 1; columns likewise, the column fold
+// applied once per loaded row.  Persistent waves (wave tiles dealt round-robin), 16 waves per workgroup which add into one LDS copy
+// of the gradient, one atomic per weight and workgroup (256 workgroups).
+// ---------------------------------------------------------------------------------------------
+constexpr int WNT = 1024, PF = 3;
+template <int ACTG>       // activation whose derivative scales dY (0: none)
+__global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R, int n_rr, int n_cg) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];       // [9][Cin] + 1
+    const int cpl = p.Cin >> 2, wpw = 64 / cpl;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane % cpl, slot = lane / cpl;
+    const int H = p.H, W = p.W, Cin = p.Cin;
+    const bool refl = p.reflect != 0;
+    f32x4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int ntile = p.B * n_rr * n_cg, nwave = gridDim.x * (WNT / 64);
+#pragma unroll 1
+    for (int tile = blockIdx.x * (WNT / 64) + wave; tile < ntile; tile += nwave) {
+        const int cg = tile % n_cg, rr = (tile / n_cg) % n_rr, b = tile / (n_cg * n_rr);
+        const int ix = cg * wpw + slot;
+        const bool col_ok = ix < W;
+        const int ixc = min(ix, W - 1);
+        // columns of the three g values of a row: b = 0 <-> ox = ix + 1, b = 1 <-> ix, b = 2 <-> ix - 1; zero outside the image
+        const float m0 = (col_ok && ix + 1 < W) ? 1.f : 0.f, m1 = col_ok ? 1.f : 0.f, m2 = (col_ok && ix >= 1) ? 1.f : 0.f;
+        const int c0 = min(ix + 1, W - 1), c2 = max(ixc - 1, 0);
+        const float f0 = (refl && ix == 1) ? 1.f : 0.f, f2 = (refl && ix == W - 2) ? 1.f : 0.f;      // column folds
+        // one descriptor per tensor and image, 32-bit lane offsets that never change during the run, the row as the scalar offset
+        const size_t img = (size_t)b * H * W;
+        const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + img), 0, H * W * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y + img), 0, H * W * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + img * Cin), 0, H * W * Cin * 4, 0x00020000);
+        const unsigned o0 = (unsigned)c0 * 4u, o1 = (unsigned)ixc * 4u, o2 = (unsigned)c2 * 4u, ox = (unsigned)(ixc * Cin + kq * 4) * 4u;
+        const int grow_b = W * 4, xrow_b = W * Cin * 4;
+        // Row gy of g at my three columns in two halves: the LOADS (raw dY, Y; what the ring keeps in flight) and the arithmetic on
+        // them (activation derivative, masks, column fold) at the step that consumes the row -- arithmetic next to the load would make
+        // the loop wait for its youngest load.  No branches either (a load behind a branch costs a full vmcnt(0) wait at the join):
+        // rows outside the image read a clamped row and are multiplied by zero.
+        struct Raw { float d[3], y[ACTG != 0 ? 3 : 1]; };
+        auto gload = [&](int gy, Raw& o) {
+            const int rb = min(max(gy, 0), H - 1) * grow_b;
+            o.d[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, o0, rb, 0));
+            o.d[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, o1, rb, 0));
+            o.d[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dr, o2, rb, 0));
+            if constexpr (ACTG != 0) {
+                o.y[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o0, rb, 0));
+                o.y[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o1, rb, 0));
+                o.y[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, o2, rb, 0));
+            }
+        };
+        // rm: 1 if row gy exists and the step that consumes it is inside the run (both wave-uniform), else 0
+        auto gfin = [&](const Raw& r, float rm, float (&o)[3]) {
+            float d0 = r.d[0], d1 = r.d[1], d2 = r.d[2];
+            if constexpr (ACTG != 0) {
+                d0 *= act_grad_from_out(r.y[0], ACTG);
+                d1 *= act_grad_from_out(r.y[1], ACTG);
+                d2 *= act_grad_from_out(r.y[2], ACTG);
+            }
+            d0 *= m0 * rm; d1 *= m1 * rm; d2 *= m2 * rm;
+            o[0] = fmaf(f0, d2, d0);
+            o[1] = d1;
+            o[2] = fmaf(f2, d0, d2);
+        };
+        const int iy0 = rr * R, iy1 = min(iy0 + R, H);
+        auto xload = [&](int iy) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ox, min(iy, H - 1) * xrow_b, 0)); };
+        auto exists = [&](int gy) { return (gy >= 0 && gy < H) ? 1.f : 0.f; };
+        // PF rows of x and of g in flight: ring slot k holds x row iy + k and g row iy + 1 + k of the current group of PF steps; a slot
+        // is refilled at the end of the step that consumed it, so the loads of the next PF rows fly under this group's arithmetic.
+        // Steps past the end of the run read clamped rows and see a zero window.
+        float prev[3], cur[3];
+        {
+            Raw a, c;
+            gload(iy0 - 1, a);
+            gload(iy0, c);
+            gfin(a, exists(iy0 - 1), prev);
+            gfin(c, 1.f, cur);
+        }
+        f32x4 xq[PF];
+        Raw gq[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            gload(iy0 + 1 + k, gq[k]);
+            xq[k] = xload(iy0 + k);
+        }
+#pragma unroll 1
+        for (int iyg = iy0; iyg < iy1; iyg += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int iy = iyg + k;
+                const float live = iy < iy1 ? 1.f : 0.f;
+                float next[3];
+                gfin(gq[k], exists(iy + 1), next);
+                // window rows by tap: ky = 0 <-> g row iy + 1, ky = 1 <-> iy, ky = 2 <-> iy - 1; row folds on the ORIGINAL rows
+                float g0[3], g1[3], g2[3];
+                const float r0 = (refl && iy == 1) ? live : 0.f, r2 = (refl && iy == H - 2) ? live : 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    g0[j] = fmaf(r0, prev[j], next[j] * live);
+                    g1[j] = cur[j] * live;
+                    g2[j] = fmaf(r2, next[j], prev[j] * live);
+                }
+                bsum += g1[1];                           // g at (iy, ix): masked by m1, and the column folds do not touch b = 1
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[0 * 3 + j] += xq[k] * g0[j];
+                    acc[1 * 3 + j] += xq[k] * g1[j];
+                    acc[2 * 3 + j] += xq[k] * g2[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    prev[j] = cur[j];
+                    cur[j] = next[j];
+                }
+                xq[k] = xload(iy + PF);
+                gload(iy + 1 + PF, gq[k]);
+                // keep the steps' loads in program order: the counter waits are in-order, and a scheduler that clusters the loads of
+                // several steps ends up waiting for the youngest one
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // pixel slots of a wave: butterfly over the lane bits above the chunk index
+    for (int off = cpl; off < 64; off <<= 1) {
+        bsum += __shfl_xor(bsum, off, 64);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][j] += __shfl_xor(acc[t][j], off, 64);
+    }
+    // the sixteen waves add into one LDS copy of the gradient (ds_add_f32), then one atomic per weight and workgroup
+    const int nw = 9 * Cin;
+    for (int e = threadIdx.x; e <= nw; e += WNT) sred[e] = 0.f;        // [9][Cin] + the bias sum
+    __syncthreads();
+    if (lane < cpl) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(sred + t * Cin + lane * 4 + j, acc[t][j]);
+    }
+    if (lane == 0) atomicAdd(sred + nw, bsum);
+    __syncthreads();
+#ifdef HEAD_DBG_NOATOM          // timing cut (tools/build_variant.py --flag=-DHEAD_DBG_NOATOM): wrong results by construction
+    if (sred[0] == 12345.678f)
+#endif
+    for (int e = threadIdx.x; e < nw; e += WNT) atomicAdd(p.dw + e, sred[e]);
+    if (p.dbias && threadIdx.x == 0) atomicAdd(p.dbias, sred[nw]);
+}
+
+// One workgroup per CU (fewer measured slower at every scale: tools/head_bench.py with DVS_HEAD_WGRAD_WGS); rows per wave tile: the run
+// length in [8, 32] with the cheapest schedule -- rounds of the persistent waves x (R + about half a step of extra g rows).
+inline void launch_wgrad_in(const HeadParams& p, hipStream_t st) {
+    static const int forced = [] { const char* e = getenv("DVS_HEAD_WGRAD_WGS"); return e ? atoi(e) : 0; }();
+    const int cpl = p.Cin / 4, wpw = 64 / cpl, n_cg = (p.W + wpw - 1) / wpw;
+    const int G = forced > 0 ? forced : 256;
+    const long waves = (long)G * (WNT / 64);
+    int bestR = p.H < 8 ? p.H : 8;
+    double best = 1e30;
+    for (int R = bestR; R <= 32 && R <= p.H; ++R) {
+        const long tiles = (long)p.B * ((p.H + R - 1) / R) * n_cg;
+        const long rounds = (tiles + waves - 1) / waves;
+        const double t = (double)rounds * (R + 0.5);
+        if (t <= best) { best = t; bestR = R; }
+    }
+    const int n_rr = (p.H + bestR - 1) / bestR;
+    const long tiles = (long)p.B * n_rr * n_cg;
+    int grid = (int)((tiles + WNT / 64 - 1) / (WNT / 64));
+    if (grid > G) grid = G;
+    const size_t lds = ((size_t)9 * p.Cin + 1) * sizeof(float);
+    if (p.act == ACT_SIGMOID) hipLaunchKernelGGL(head_wgrad_in_kernel<ACT_SIGMOID>, dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
+    else hipLaunchKernelGGL(head_wgrad_in_kernel<0>, dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
+}
+
 inline bool rows_form_ok(const HeadParams& p, int cout) {
     static const bool enabled = [] { const char* e = getenv("DVS_HEAD_ROWS"); return !(e && e[0] == '0'); }();
     const int cpl = p.Cin / 4;
@@ -460,7 +641,11 @@ int run(const HeadParams& p0, int op, hipStream_t st) {
     const int Ktot = p.k * p.k * p.Cin, M = p.B * p.H * p.W;
     const size_t wbytes = (size_t)COUT * Ktot * sizeof(float);
     if (op != 1 && rows_form_ok(p, COUT)) {
-        if (p.k == 3) launch_rows<COUT, 3>(p, op, st);
+        static const bool in_form = [] { const char* e = getenv("DVS_HEAD_WGRAD_IN"); return !(e && e[0] == '0'); }();
+        if (op == 2 && COUT == 1 && p.k == 3 && p.pad == 1 && in_form && (p.act == 0 || p.act == ACT_SIGMOID) &&
+            (size_t)p.H * p.W * p.Cin * 4 < ((size_t)1 << 31))
+            launch_wgrad_in(p, st);
+        else if (p.k == 3) launch_rows<COUT, 3>(p, op, st);
         else launch_rows<COUT, 1>(p, op, st);
         return DVS_OK;
     }
