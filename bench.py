@@ -412,7 +412,7 @@ def dav2_side(device, with_cpu, batches=(1, 8)):
             finally:
                 _dvs_lib.set_precision("fp32")
         res["bf16_mode"] = {"batch": Bb, "value": Bb / dtb, "ms_per_forward": dtb * 1e3,
-                            "dtype": "bf16 operands x fp32 accumulate in the token GEMMs / convolutions, fp32 attention, LayerNorm, GELU (opt-in mode)",
+                            "dtype": "bf16 operands x fp32 accumulate in the token GEMMs, attention products and convolutions; fp32 softmax, LayerNorm, GELU (opt-in mode)",
                             "rel_max_diff_of_depth_vs_fp32": float((y16.float() - y32).abs().max() / y32.abs().max())}
     # the trainable path (autograd on): forward + backward of a scalar loss, batch 4
     Bt = 4
