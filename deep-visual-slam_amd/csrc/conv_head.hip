@@ -293,8 +293,11 @@ __global__ __launch_bounds__(HNT) void head_fwd_rows_kernel(HeadParams p) {
     float bv[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) bv[c] = p.bias ? p.bias[c] : 0.f;
-    const int rows = p.B * p.H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    // a workgroup walks a run of CONSECUTIVE rows: the two rows it shares with the next step come from its own L1 / L2 (rows dealt
+    // round-robin were fetched by three workgroups, i.e. three XCDs: 3x the HBM reads)
+    const int rows = p.B * p.H, per = (rows + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int row_end = min(rows, ((int)blockIdx.x + 1) * per);
+    for (int row = blockIdx.x * per; row < row_end; ++row) {
         const int b = row / p.H, oy = row - b * p.H;
         const float* rp[KS];
         bool rok[KS];
@@ -627,7 +630,9 @@ void launch_rows(const HeadParams& p, int op, hipStream_t st) {
     const int rows = p.B * p.H;
     if constexpr (COUT * KS * KS <= 18) {
         if (op == 0) {
-            hipLaunchKernelGGL((head_fwd_rows_kernel<COUT, KS>), dim3(rows < 4096 ? rows : 4096), dim3(HNT), 0, st, p);
+            static const int fwd_wgs = [] { const char* e = getenv("DVS_HEAD_FWD_WGS"); return e ? atoi(e) : 1024; }();
+            const int per = (rows + fwd_wgs - 1) / fwd_wgs;
+            hipLaunchKernelGGL((head_fwd_rows_kernel<COUT, KS>), dim3((rows + per - 1) / per), dim3(HNT), 0, st, p);
         } else {
             const size_t lds = ((size_t)4 * (p.Cin / 4) * COUT * KS * KS * 4 + 4 * COUT) * sizeof(float);
             hipLaunchKernelGGL((head_wgrad_rows_kernel<COUT, KS>), dim3(rows < 512 ? rows : 512), dim3(HNT), lds, st, p);

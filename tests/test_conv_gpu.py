@@ -145,7 +145,12 @@ def test_unsupported_shapes_are_reported(gpu_device):
 
 
 @pytest.mark.parametrize("cin,cout,k,refl,act,H,W", [(16, 1, 3, True, "sigmoid", 40, 56), (128, 1, 3, True, "sigmoid", 9, 13),
-                                                    (256, 6, 1, False, None, 7, 9), (32, 1, 3, True, "sigmoid", 3, 4)])
+                                                    (256, 6, 1, False, None, 7, 9), (32, 1, 3, True, "sigmoid", 3, 4),
+                                                    # the input-indexed weight gradient: zero padding, no activation, widths that are not
+                                                    # a multiple of a wave's columns, one-column waves (Cin = 256), runs longer than H
+                                                    (16, 1, 3, False, None, 37, 45), (64, 1, 3, True, None, 33, 18),
+                                                    (256, 1, 3, True, "sigmoid", 10, 7), (32, 1, 3, False, "sigmoid", 2, 2),
+                                                    (16, 1, 3, True, "sigmoid", 70, 33)])
 def test_head_conv(gpu_device, cin, cout, k, refl, act, H, W):
     """Disparity heads (reflect-pad 3x3 -> 1 channel -> sigmoid) and PoseNet's 1x1 -> 6 channels."""
     from deep_visual_slam_amd import nn_ops

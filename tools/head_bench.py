@@ -41,4 +41,19 @@ for cin, H, W in ((16, 480, 640), (32, 240, 320), (64, 120, 160), (128, 60, 80))
     torch.cuda.synchronize()
     us = a.elapsed_time(e) / 20 * 1e3
     mb = (x.numel() + 2 * y.numel()) * 4 / 1e6
-    print("Cin %3d  %3dx%3d  %7.1f us  %6.1f MB  %5.2f TB/s   dw err %.1e  db err %.1e" % (cin, H, W, us, mb, mb / us, ew, eb))
+    yo = torch.empty_like(y)
+
+    def fwd():
+        check(_lib.lib().dvs_conv2d_head_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), yo.data_ptr(), C.byref(d), ACT["sigmoid"], _lib.stream()),
+              "dvs_conv2d_head_fwd")
+    for _ in range(3):
+        fwd()
+    a.record()
+    for _ in range(20):
+        fwd()
+    e.record()
+    torch.cuda.synchronize()
+    usf = a.elapsed_time(e) / 20 * 1e3
+    ef = float((yo - y).abs().max())
+    print("Cin %3d  %3dx%3d  wgrad %7.1f us  %6.1f MB  %5.2f TB/s   dw err %.1e  db err %.1e | fwd %7.1f us  %5.2f TB/s  err %.1e" % (
+        cin, H, W, us, mb, mb / us, ew, eb, usf, (x.numel() + y.numel()) * 4 / 1e6 / usf, ef))
