@@ -635,7 +635,12 @@ void launch_rows(const HeadParams& p, int op, hipStream_t st) {
             hipLaunchKernelGGL((head_fwd_rows_kernel<COUT, KS>), dim3((rows + per - 1) / per), dim3(HNT), 0, st, p);
         } else {
             const size_t lds = ((size_t)4 * (p.Cin / 4) * COUT * KS * KS * 4 + 4 * COUT) * sizeof(float);
-            hipLaunchKernelGGL((head_wgrad_rows_kernel<COUT, KS>), dim3(rows < 512 ? rows : 512), dim3(HNT), lds, st, p);
+            // every workgroup ends with COUT * k * k * Cin same-address atomics: a small map (PoseNet's 1x1 head: 24 x 15 x 20 pixels
+            // of 256 channels) gets one workgroup per 32 K elements, not one per row (360 workgroups there: 56 us, most of it atomics)
+            const long elems = (long)rows * p.W * p.Cin;
+            int wgs = (int)(elems >> 15);
+            wgs = wgs < 16 ? 16 : (wgs > 512 ? 512 : wgs);
+            hipLaunchKernelGGL((head_wgrad_rows_kernel<COUT, KS>), dim3(rows < wgs ? rows : wgs), dim3(HNT), lds, st, p);
         }
     }
 }
