@@ -102,46 +102,57 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
         x_goff[j] = x_is2[j] ? sx * p.C2 + (c - p.C1) : (p.up ? sx >> 1 : sx) * p.C1 + c;
         x_loff[j] = px * CS + c;
     }
-    f32x4 rx[X_LOADS];
-    auto load_row = [&](int pr) {                        // padded row pr = source row refl(pr - 1)
-        const int sr = reflect_i(pr - 1, p.H);
+    // NS register sets: a row is loaded NS stages before the stage that stores it into the ring (a stage is ~1 us of MFMAs, an HBM
+    // round trip under load several: with one set every stage ended waiting for the row it had just asked for)
+#ifdef THIN_NS
+    constexpr int NS = THIN_NS;
+#else
+    constexpr int NS = 2;                                // (three and four sets measured the same; they cost a workgroup per CU)
+#endif
+    f32x4 rx[NS][X_LOADS];
+    auto load_row = [&](int pr, auto set) {              // padded row pr = source row refl(pr - 1)
+        constexpr int S = decltype(set)::value;
+        const int sr = reflect_i(min(pr, p.H + 1) - 1, p.H);
         const float* r1 = p.x + ((size_t)b * H1 + (p.up ? sr >> 1 : sr)) * W1 * p.C1;
         const float* r2 = p.C2 > 0 ? p.x2 + ((size_t)b * p.H + sr) * p.W * p.C2 : r1;
 #pragma unroll
-        for (int j = 0; j < X_LOADS; ++j) rx[j] = *reinterpret_cast<const f32x4*>((x_is2[j] ? r2 : r1) + x_goff[j]);
+        for (int j = 0; j < X_LOADS; ++j) rx[S][j] = *reinterpret_cast<const f32x4*>((x_is2[j] ? r2 : r1) + x_goff[j]);
     };
-    auto store_row = [&](int pr) {
+    auto store_row = [&](int pr, auto set) {
+        constexpr int S = decltype(set)::value;
         float* dst = Ps + (pr & 3) * ROWF;
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j)
-            if (x_ok[j]) *reinterpret_cast<f32x4*>(dst + x_loff[j]) = rx[j];
+            if (x_ok[j]) *reinterpret_cast<f32x4*>(dst + x_loff[j]) = rx[S][j];
     };
 
     // ---- dY staging (x activation derivative) + bias gradient
-    f32x4 rd[D_LOADS], ry[D_LOADS], bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rd[NS][D_LOADS], ry[NS][D_LOADS], bsum = {0.f, 0.f, 0.f, 0.f};
     const int d_c = (tid % DV) * 4;
     const bool d_ok = tid < D_VECS;                       // wave-uniform (D_VECS is a multiple of 64)
-    auto load_d = [&](int oy) {
+    auto load_d = [&](int oy, auto set) {
+        constexpr int S = decltype(set)::value;
         if (d_ok) {
 #pragma unroll
             for (int j = 0; j < D_LOADS; ++j) {
-                const size_t o = (((size_t)b * p.H + oy) * p.W + x0 + (tid + NT * j) / DV) * Cout + d_c;
-                rd[j] = *reinterpret_cast<const f32x4*>(p.dy + o);
-                if (p.dact) ry[j] = *reinterpret_cast<const f32x4*>(p.y + o);
+                const size_t o = (((size_t)b * p.H + min(oy, p.H - 1)) * p.W + x0 + (tid + NT * j) / DV) * Cout + d_c;
+                rd[S][j] = *reinterpret_cast<const f32x4*>(p.dy + o);
+                if (p.dact) ry[S][j] = *reinterpret_cast<const f32x4*>(p.y + o);
             }
         }
     };
-    auto store_d = [&](int buf) {
+    auto store_d = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
         if (d_ok) {
 #pragma unroll
             for (int j = 0; j < D_LOADS; ++j) {
-                f32x4 v = rd[j];
+                f32x4 v = rd[S][j];
                 if (p.dact == ACT_ELU) {                  // 1 + min(y, 0)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fminf(ry[j][e], 0.f), v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], fminf(ry[S][j][e], 0.f), v[e]);
                 } else if (p.dact) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(ry[j][e], p.dact);
+                    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_out(ry[S][j][e], p.dact);
                 }
                 *reinterpret_cast<f32x4*>(&Ds[buf][(tid + NT * j) / DV][d_c]) = v;
                 bsum += v;
@@ -171,52 +182,119 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[i][r] = 0.f;
 
+    using S0 = std::integral_constant<int, 0>;
     if (oy_begin < oy_end) {
         for (int pr = oy_begin; pr < oy_begin + 3; ++pr) {
-            load_row(pr);
-            store_row(pr);
+            load_row(pr, S0{});
+            store_row(pr, S0{});
         }
-        load_d(oy_begin);
-        store_d(0);
+        load_d(oy_begin, S0{});
+        store_d(0, S0{});
+        static_for_thin<0, NS - 1>([&](auto k) {          // set k: the row stage oy_begin + k stores
+            load_row(oy_begin + 3 + k.value, k);
+            load_d(oy_begin + 1 + k.value, k);
+        });
+        // the ring slot and the dY buffer that a one- or two-row chunk never writes are still read (times zero) by the dead stages
+        for (int i = tid; i < ROWF; i += NT) Ps[((oy_begin + 3) & 3) * ROWF + i] = 0.f;
+        for (int i = tid; i < SEG * MT; i += NT) (&Ds[1][0][0])[i] = 0.f;
     }
     __syncthreads();
     int buf = 0;
-#pragma unroll 1
-    for (int oy = oy_begin; oy < oy_end; ++oy) {
+    // stage oy with register set S = (oy - oy_begin) % NS: ask for the row / dY row that stage oy + NS - 1 will store (into the set
+    // the previous stage emptied), multiply, store what set S holds (asked for NS - 1 stages ago) for stage oy + 1.  Rows past the
+    // end of the chunk are never asked for or stored; the dead stages that fill the last group multiply zeros.
+    auto stage = [&](int oy, auto set) {
+        constexpr int S = decltype(set)::value;
+        using Free = std::integral_constant<int, (S + NS - 1) % NS>;
         const bool more = oy + 1 < oy_end;
-        if (more) {
-            load_row(oy + 3);                             // global loads stay in flight across the MFMAs
-            load_d(oy + 1);
+#ifndef THIN_DBG          // timing cuts (tools/build_variant.py --flag=-DTHIN_DBG=<bits>; wrong results): 1 no global loads in the loop,
+#define THIN_DBG 0        // 2 no MFMAs, 4 no LDS stores in the loop, 8 no barrier in the loop
+#endif
+        if (oy + NS < oy_end && !(THIN_DBG & 1)) {
+            load_row(oy + 2 + NS, Free{});                // global loads stay in flight across NS - 1 stages of MFMAs
+            load_d(oy + NS, Free{});
         }
         const float* Ab = &Ds[buf][0][0] + a_lane;
         const float* Bb[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) Bb[i] = Ps + ((oy + t_ky[i]) & 3) * ROWF + t_off[i] + b_lane;
+        const float live = oy < oy_end ? 1.f : 0.f;
+        // operands of k-step t + 1 are read before the MFMAs of step t, and the order is pinned: left alone the compiler puts every
+        // ds_read right in front of the two MFMAs it feeds and waits lgkmcnt(0) there -- one LDS round trip per 64 cycles of matrix
+        // work (the 16-channel forms ran at 0.36 of the MFMA rate for it)
+        float aq[2], bq[2][TPW];
+        aq[0] = Ab[0];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) bq[0][i] = Bb[i][0];
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
-            const float a = Ab[t * KS * MT];
+            if (t + 1 < STEPS) {
+                aq[(t + 1) & 1] = Ab[(t + 1) * KS * MT];
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) acc[i] = mma(a, Bb[i][t * KS * CS], acc[i]);
+                for (int i = 0; i < TPW; ++i) bq[(t + 1) & 1][i] = Bb[i][(t + 1) * KS * CS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float a = aq[t & 1] * live;
+            if constexpr (THIN_DBG & 2) {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i][0] += a * bq[t & 1][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i] = mma(a, bq[t & 1][i], acc[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            store_row(oy + 3);                            // slot (oy - 1) & 3: not read by this stage
-            store_d(buf ^ 1);
+        if (more && !(THIN_DBG & 4)) {
+            store_row(oy + 3, set);                       // slot (oy - 1) & 3: not read by this stage
+            store_d(buf ^ 1, set);
         }
-        __syncthreads();
+        if (!(THIN_DBG & 8)) __syncthreads();
         buf ^= 1;
-    }
+    };
+    // (stages come in groups of NS, one per register set, without a branch between them: a conditional stage made the compiler keep
+    // two copies of the accumulators)
+#pragma unroll 1
+    for (int oy = oy_begin; oy < oy_end; oy += NS) static_for_thin<0, NS>([&](auto k) { stage(oy + k.value, k); });
 
     // ---- epilogue: dW[co][tap][ci] += acc.  C/D maps: 32x32: co = (r&3) + 8 (r>>2) + 4 (lane>>5), ci = lane & 31;
     //      16x16: co = 4 (lane>>4) + r, ci = lane & 15
+    if constexpr (PWAVES > 1) {
+        // The waves of the 16-channel forms split the PIXELS: each holds a partial of the whole dW.  Added to the arena wave by wave
+        // that was 4 x 480 same-address atomics per weight (~85 ns each: 160 us, more than the kernel's arithmetic -- with every
+        // phase of the row loop cut out it still took 195 us); the waves now add into one LDS copy first (the ring is free: the row
+        // loop ended on a barrier) and the workgroup adds that once.
+        static_assert(Cout * 9 * CIN <= 4 * ROWF, "dW fits the ring");
+        float* sw = Ps;
+        for (int i = tid; i < Cout * Ktot; i += NT) sw[i] = 0.f;
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if (!t_ok[i]) continue;
-        const int q = tw + TWAVES * i;
-        const int kk = (q / CT) * CIN + (q % CT) * MT + col;
+        for (int i = 0; i < TPW; ++i) {
+            if (!t_ok[i]) continue;
+            const int q = tw + TWAVES * i;
+            const int kk = (q / CT) * CIN + (q % CT) * MT + col;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int co = (MT == 32) ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r;
-            atomicAdd(p.dw + (size_t)co * Ktot + kk, acc[i][r]);
+            for (int r = 0; r < NR; ++r) atomicAdd(sw + (4 * (lane >> 4) + r) * Ktot + kk, acc[i][r]);
+        }
+        __syncthreads();
+        // every workgroup finishes at the same time: each starts its pass over dW somewhere else, so that the atomics in flight at any
+        // moment are spread over the addresses instead of queueing on the same ones
+        constexpr int NW = Cout * 9 * CIN;
+        const int rot = (int)((blockIdx.x * 7u) % (unsigned)(NW / NT)) * NT;
+        for (int i = tid; i < NW; i += NT) {
+            const int j = i + rot < NW ? i + rot : i + rot - NW;
+            atomicAdd(p.dw + j, sw[j]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (!t_ok[i]) continue;
+            const int q = tw + TWAVES * i;
+            const int kk = (q / CT) * CIN + (q % CT) * MT + col;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int co = (MT == 32) ? (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) : 4 * (lane >> 4) + r;
+                atomicAdd(p.dw + (size_t)co * Ktot + kk, acc[i][r]);
+            }
         }
     }
     if (p.dbias) {
