@@ -612,8 +612,9 @@ void launch_wgrad(StemParams p, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    static const int cap = [] { const char* e = getenv("DVS_STEM_WGRAD_PER_CU"); return e ? atoi(e) : 3; }();
     const int per_cu = (int)(160 * 1024 / lds);
-    int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+    int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > cap ? cap : per_cu));
     if (blocks > p.tiles) blocks = p.tiles;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(SNT), lds, st, p);
 }

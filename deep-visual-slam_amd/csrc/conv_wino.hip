@@ -438,6 +438,9 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
             for (int k = 0; k < 4; ++k)
                 rv[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ob, (k >> 1) * row_b + (k & 1) * col_b, 0));
         }
+        // (fence: the scheduler otherwise starts reading accumulators among these loads, runs out of registers and spills residual
+        // values as they arrive -- every spill store waits for its load, i.e. the 64 loads went one at a time: + 40 % on layer 1)
+        if constexpr (!KSPLIT) __builtin_amdgcn_sched_barrier(0);
     }
     // (a - b on a register pair as ONE v_pk_add_f32 with negated second operand: left to itself the compiler emits two v_sub_f32)
     auto pk_sub = [](f32x2 a, f32x2 b) __attribute__((always_inline)) {
@@ -494,6 +497,9 @@ __global__ __launch_bounds__(NT, 1) void wino_fwd_kernel(WinoParams p) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yr, tbase[i + e], (k >> 1) * row_b + (k & 1) * col_b, 0);
                     }
                 }
+                // RES: the 64 residual values already take a quarter of the vector registers; without a fence the scheduler starts the
+                // accumulator reads of several tile pairs at once and spills (a reload then waits, in order, for every residual load)
+                if constexpr (RES) __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (want_stats) fast_body(std::true_type{});
