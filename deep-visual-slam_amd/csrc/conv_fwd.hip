@@ -489,8 +489,13 @@ void launch_dma(const FwdParams& p, hipStream_t st, int slot) {
         // gradients of layer 4).
         static const bool splitk = [] { const char* e = getenv("DVS_CONV_SPLITK"); return !(e && e[0] == '0'); }();
         const int tiles = grid.x * grid.y, nC = p.s.Cin / BK;
-        if (splitk && !dvs::deterministic() && !p.stats && tiles < 200 && nC >= 2 && (p.s.Cout & 3) == 0) {
-            int want = min(nC, (256 + tiles - 1) / tiles);
+        // (200 ... 320 tiles: one workgroup per CU and a K of thousands -- upconv_4_0's data gradient, 284 tiles of 72 stages: 148 us;
+        // split towards 1 024 workgroups: 111 us.  DVS_SPLITK_TILES / DVS_SPLITK_TARGET for experiments)
+        static const int sk_tiles = [] { const char* e = getenv("DVS_SPLITK_TILES"); return e ? atoi(e) : 320; }();
+        static const int sk_target = [] { const char* e = getenv("DVS_SPLITK_TARGET"); return e ? atoi(e) : 0; }();
+        if (splitk && !dvs::deterministic() && !p.stats && tiles < sk_tiles && nC >= 2 && (p.s.Cout & 3) == 0) {
+            const int target = sk_target > 0 ? sk_target : (tiles < 200 ? 256 : 1024);
+            int want = min(nC, (target + tiles - 1) / tiles);
             const int per = (nC + want - 1) / want;
             q.ksplit = (nC + per - 1) / per;
         }
