@@ -537,29 +537,34 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
         x_goff[j] = clampi(col, p.W) * CK + c;
         x_loff[j] = e * CS + c;
     }
-    f32x4 rd[X_LOADS], ry[X_LOADS];
-    bool row_in = false;
+    // NS register sets: a dZ row is asked for NS stages before the stage that stores it into the ring (see thin_wgrad_kernel).  Two sets
+    // only for the one-wave-per-SIMD form (upconv_1_1): the others hide the round trip behind their second and third workgroup, and
+    // the second copy of the stage costs them one
+    constexpr int NS = (NTN == 3) ? 2 : 1;
+    f32x4 rd[NS][X_LOADS], ry[NS][X_LOADS];
     const bool elu = p.dact == ACT_ELU;
-    auto load_row = [&](int d) {                          // dZ row d (may be -1 or H: zeros)
-        row_in = (unsigned)d < (unsigned)p.H;
+    auto load_row = [&](int d, auto set) {                // dZ row d (may be -1 or H: zeros)
+        constexpr int S = decltype(set)::value;
         const size_t ro = ((size_t)b * p.H + clampi(d, p.H)) * p.W * CK;
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j) {
-            rd[j] = *reinterpret_cast<const f32x4*>(p.dy + ro + x_goff[j]);
-            if (p.dact) ry[j] = *reinterpret_cast<const f32x4*>(p.y + ro + x_goff[j]);
+            rd[S][j] = *reinterpret_cast<const f32x4*>(p.dy + ro + x_goff[j]);
+            if (p.dact) ry[S][j] = *reinterpret_cast<const f32x4*>(p.y + ro + x_goff[j]);
         }
     };
-    auto store_row = [&](int d) {
+    auto store_row = [&](int d, auto set) {
+        constexpr int S = decltype(set)::value;
+        const bool row_in = (unsigned)d < (unsigned)p.H;
         float* dst = Ps + ((d + 1) & 3) * ROWF;
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j)
             if (x_ok[j]) {
-                f32x4 v = rd[j];
+                f32x4 v = rd[S][j];
                 const bool in = row_in && x_in[j];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // ELU'(y) = 1 + min(y, 0): two instructions, no branch (the generic form is a switch per element)
-                    const float g = elu ? fmaf(v[e], fminf(ry[j][e], 0.f), v[e]) : (p.dact ? v[e] * act_grad_from_out(ry[j][e], p.dact) : v[e]);
+                    const float g = elu ? fmaf(v[e], fminf(ry[S][j][e], 0.f), v[e]) : (p.dact ? v[e] * act_grad_from_out(ry[S][j][e], p.dact) : v[e]);
                     v[e] = in ? g : 0.f;
                 }
                 float2* d2 = reinterpret_cast<float2*>(dst + x_loff[j]);
@@ -592,17 +597,20 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
     };
     zero_acc();
 
+    using S0 = std::integral_constant<int, 0>;
     if (iy_begin < iy_end) {
         for (int d = iy_begin - 1; d <= iy_begin + 1; ++d) {
-            load_row(d);
-            store_row(d);
+            load_row(d, S0{});
+            store_row(d, S0{});
         }
+        static_for_thin<0, NS - 1>([&](auto k) { load_row(iy_begin + 2 + k.value, k); });      // set k: the row stage iy_begin + k stores
     }
     __syncthreads();
-#pragma unroll 1
-    for (int iy = iy_begin; iy < iy_end; ++iy) {
+    auto stage = [&](int iy, auto set) {
+        constexpr int S = decltype(set)::value;
+        using Free = std::integral_constant<int, (S + NS - 1) % NS>;
         const bool more = iy + 1 < iy_end;
-        if (more) load_row(iy + 2);
+        if (iy + NS < iy_end) load_row(iy + 1 + NS, Free{});      // in flight across NS stages (NS = 1: this one)
         // operands of one tap (all k-steps, all pixel tiles) / its MFMAs.  The LDS reads of tap i + 1 are issued before the
         // MFMAs of tap i and fenced there (sched_barrier): left alone, the scheduler sinks every ds_read next to its MFMA and
         // the wave pays one LDS round trip per k-step.
@@ -689,9 +697,14 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
                     }
                 }
         }
-        if (more) store_row(iy + 2);
+        if (more) store_row(iy + 2, set);
         __syncthreads();
-    }
+    };
+#pragma unroll 1
+    for (int iy = iy_begin; iy < iy_end; iy += NS)
+        static_for_thin<0, NS>([&](auto k) {
+            if (k.value == 0 || iy + k.value < iy_end) stage(iy + k.value, k);
+        });
 }
 
 template <int CK, int NTN, int SEG>
@@ -793,7 +806,7 @@ bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out,
     if (Cout == 16 && Cin == 16 && split_c1 == 16 && W % 128 == 0) launch_thin_dgrad<16, 1, 128>(p, st);            // upconv_0_1
     else if (Cout == 16 && Cin == 32 && split_c1 == 0 && W % 64 == 0) launch_thin_dgrad<16, 2, 64>(p, st);          // upconv_0_0
     else if (Cout == 32 && Cin % 48 == 0 && Cin <= 192 && split_c1 % 16 == 0 && W % 64 == 0)
-        launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1
+        launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1 (the two-tile form at two workgroups per CU: 696 against 565 us)
     else if (Cout == 32 && Cin % 32 == 0 && Cin <= 128 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 2, 64>(p, st);
     else return false;
     return true;
