@@ -182,8 +182,6 @@ __global__ __launch_bounds__(SNT) void stem_wgrad_kernel(StemParams p) {
 #pragma unroll
         for (int s = 0; s < TPX / 2; ++s) {
             // pixels 2s, 2s+1: output row r = (2s) / 64, column c = (2s) % 64 (+ h) -> patch origin (2r, 2c)
-            constexpr int dummy = 0;
-            (void)dummy;
             const int pix_off = (2 * ((2 * s) >> 6)) * PSTRIDE + 2 * ((2 * s) & 63);
             const float a = dyt[(2 * s) * 64 + a_off];
             float bv[TNW];
