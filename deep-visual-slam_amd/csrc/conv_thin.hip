@@ -24,6 +24,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef THIN_DBG          // timing cuts of the row loops (tools/build_variant.py --flag=-DTHIN_DBG=<bits>; wrong results): 1 no global loads,
+#define THIN_DBG 0        // 2 no MFMAs, 4 no LDS stores, 8 no barrier, 16 no output stores (data gradient)
+#endif
+
 namespace dvsconv {
 namespace {
 
@@ -207,9 +211,6 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
         constexpr int S = decltype(set)::value;
         using Free = std::integral_constant<int, (S + NS - 1) % NS>;
         const bool more = oy + 1 < oy_end;
-#ifndef THIN_DBG          // timing cuts (tools/build_variant.py --flag=-DTHIN_DBG=<bits>; wrong results): 1 no global loads in the loop,
-#define THIN_DBG 0        // 2 no MFMAs, 4 no LDS stores in the loop, 8 no barrier in the loop
-#endif
         if (oy + NS < oy_end && !(THIN_DBG & 1)) {
             load_row(oy + 2 + NS, Free{});                // global loads stay in flight across NS - 1 stages of MFMAs
             load_d(oy + NS, Free{});
@@ -610,7 +611,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
         constexpr int S = decltype(set)::value;
         using Free = std::integral_constant<int, (S + NS - 1) % NS>;
         const bool more = iy + 1 < iy_end;
-        if (iy + NS < iy_end) load_row(iy + 1 + NS, Free{});      // in flight across NS stages (NS = 1: this one)
+        if (iy + NS < iy_end && !(THIN_DBG & 1)) load_row(iy + 1 + NS, Free{});      // in flight across NS stages (NS = 1: this one)
         // operands of one tap (all k-steps, all pixel tiles) / its MFMAs.  The LDS reads of tap i + 1 are issued before the
         // MFMAs of tap i and fenced there (sched_barrier): left alone, the scheduler sinks every ds_read next to its MFMA and
         // the wave pays one LDS round trip per k-step.
@@ -637,7 +638,10 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
 #pragma unroll
                 for (int t = 0; t < PT; ++t)
 #pragma unroll
-                    for (int nt = 0; nt < NTN; ++nt) acc[t][nt] = mma(a[t][c4], wreg[nt][tap * C4 + c4], acc[t][nt]);
+                    for (int nt = 0; nt < NTN; ++nt) {
+                        if constexpr (THIN_DBG & 2) acc[t][nt][0] += a[t][c4] * wreg[nt][tap * C4 + c4];
+                        else acc[t][nt] = mma(a[t][c4], wreg[nt][tap * C4 + c4], acc[t][nt]);
+                    }
         };
         auto taps = [&](const float* row, int ky) {       // the three kx taps of weight row ky on one dZ row (fold rows only)
 #pragma unroll
@@ -668,7 +672,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
             taps(row, 2);
         }
         // C/D map: pixel = 4 (lane >> 4) + r, channel = lane & 15
-        if (any_coarse && (iy & 1)) {                     // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
+        if (any_coarse && (iy & 1) && !(THIN_DBG & 16)) { // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
             float* orow = p.dx + (((size_t)b * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + ((x0 + wave * PXW + 4 * kidx) >> 1)) * p.C1 +
                           n_base + n;
 #pragma unroll
@@ -682,7 +686,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
                     }
                 }
         }
-        if (any_direct) {
+        if (any_direct && !(THIN_DBG & 16)) {
             const int cs = p.nout - p.C1;                 // channels of the tensor these tiles belong to (C1 == 0: the input itself)
             float* base = p.C1 > 0 ? p.dx_skip : p.dx;
             float* orow = base + (((size_t)b * p.H + iy) * p.W + x0 + wave * PXW + 4 * kidx) * cs + (n_base - p.C1) + n;
@@ -697,8 +701,8 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
                     }
                 }
         }
-        if (more) store_row(iy + 2, set);
-        __syncthreads();
+        if (more && !(THIN_DBG & 4)) store_row(iy + 2, set);
+        if (!(THIN_DBG & 8)) __syncthreads();
     };
 #pragma unroll 1
     for (int iy = iy_begin; iy < iy_end; iy += NS)

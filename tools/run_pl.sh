@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
-timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_fp32.txt 2>&1; grep -n "^== conv_wgrad" -A54 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(22|52)  work"
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py -x -q -k "stem or planar or conv1" > gpurun_out/t_stem.log 2>&1; echo rc=$?; tail -3 gpurun_out/t_stem.log
+echo default; timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_fp32.txt 2>&1; grep -n "^== conv_dgrad" -A66 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(24|25|26)  work"
+for v in 1 2 16 5 13 29; do echo "THIN_DBG $v"; DVS_LIB=/root/repo/deep-visual-slam_amd/csrc/build/variant_tdbg$v.so timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_tdbg.txt 2>&1; grep -n "^== conv_dgrad" -A66 gpurun_out/per_launch_tdbg.txt | grep -E "^[0-9]+-\s+(24|25|26)  work"; done
