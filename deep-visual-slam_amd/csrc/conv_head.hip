@@ -451,7 +451,11 @@ __global__ __launch_bounds__(HNT) void head_wgrad_rows_kernel(HeadParams p) {
 // of the gradient, one atomic per weight and workgroup (256 workgroups).
 // ---------------------------------------------------------------------------------------------
 constexpr int WNT = 1024, PF = 3;
-template <int ACTG>       // activation whose derivative scales dY (0: none)
+// DG: the DATA gradient on the same walk (round 3, last): dx(iy, ix, c) = sum over taps of g'(tap) * w[tap][c] with the same folded
+// window, the lane's nine weight vectors in registers, one coalesced 16-byte store per lane and row (+ the optional fan-in gradient
+// dx_res).  The row form (head_dgrad_rows_kernel) launches one 256-thread workgroup per 64-pixel row segment -- 57 600 of them at
+// scale 0 -- and ran at 2.6x the time of its one write pass.
+template <int ACTG, bool DG = false>       // ACTG: activation whose derivative scales dY (0: none)
 __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R, int n_rr, int n_cg) {
     extern __shared__ __attribute__((aligned(16))) float sred[];       // [9][Cin] + 1
     const int cpl = p.Cin >> 2, wpw = 64 / cpl;
@@ -463,6 +467,12 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
+    f32x4 wv[DG ? 9 : 1];
+    if constexpr (DG) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * Cin + kq * 4);
+    }
+    using u32x4s = __attribute__((ext_vector_type(4))) unsigned;
     const int ntile = p.B * n_rr * n_cg, nwave = gridDim.x * (WNT / 64);
 #pragma unroll 1
     for (int tile = blockIdx.x * (WNT / 64) + wave; tile < ntile; tile += nwave) {
@@ -478,7 +488,11 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
         const size_t img = (size_t)b * H * W;
         const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + img), 0, H * W * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.y + img), 0, H * W * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + img * Cin), 0, H * W * Cin * 4, 0x00020000);
+        // (DG: the ring's x slot carries dx_res; without one the descriptor is empty and the loads return zeros)
+        const float* xsrc = DG ? (p.dx_res ? p.dx_res : p.dy) : p.x;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc + img * Cin), 0,
+                                                                             (DG && !p.dx_res) ? 0 : H * W * Cin * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(DG ? p.dx + img * Cin : nullptr, 0, DG ? H * W * Cin * 4 : 0, 0x00020000);
         const unsigned o0 = (unsigned)c0 * 4u, o1 = (unsigned)ixc * 4u, o2 = (unsigned)c2 * 4u, ox = (unsigned)(ixc * Cin + kq * 4) * 4u;
         const int grow_b = W * 4, xrow_b = W * Cin * 4;
         // Row gy of g at my three columns in two halves: the LOADS (raw dY, Y; what the ring keeps in flight) and the arithmetic on
@@ -548,12 +562,21 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
                     g1[j] = cur[j] * live;
                     g2[j] = fmaf(r2, next[j], prev[j] * live);
                 }
-                bsum += g1[1];                           // g at (iy, ix): masked by m1, and the column folds do not touch b = 1
+                if constexpr (DG) {
+                    f32x4 o = xq[k];                     // dx_res (zeros without one)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    acc[0 * 3 + j] += xq[k] * g0[j];
-                    acc[1 * 3 + j] += xq[k] * g1[j];
-                    acc[2 * 3 + j] += xq[k] * g2[j];
+                    for (int j = 0; j < 3; ++j) o += wv[0 * 3 + j] * g0[j] + wv[1 * 3 + j] * g1[j] + wv[2 * 3 + j] * g2[j];
+                    // rows past the run / columns past the image: an offset beyond the tensor, the store is dropped
+                    const unsigned so = (iy < iy1 && col_ok) ? ox : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), or_, so, min(iy, H - 1) * xrow_b, 0);
+                } else {
+                    bsum += g1[1];                       // g at (iy, ix): masked by m1, and the column folds do not touch b = 1
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        acc[0 * 3 + j] += xq[k] * g0[j];
+                        acc[1 * 3 + j] += xq[k] * g1[j];
+                        acc[2 * 3 + j] += xq[k] * g2[j];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -568,6 +591,7 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
             }
         }
     }
+    if constexpr (DG) return;
     // pixel slots of a wave: butterfly over the lane bits above the chunk index
     for (int off = cpl; off < 64; off <<= 1) {
         bsum += __shfl_xor(bsum, off, 64);
@@ -597,6 +621,7 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
 
 // One workgroup per CU (fewer measured slower at every scale: tools/head_bench.py with DVS_HEAD_WGRAD_WGS); rows per wave tile: the run
 // length in [8, 32] with the cheapest schedule -- rounds of the persistent waves x (R + about half a step of extra g rows).
+template <bool DG = false>
 inline void launch_wgrad_in(const HeadParams& p, hipStream_t st) {
     static const int forced = [] { const char* e = getenv("DVS_HEAD_WGRAD_WGS"); return e ? atoi(e) : 0; }();
     const int cpl = p.Cin / 4, wpw = 64 / cpl, n_cg = (p.W + wpw - 1) / wpw;
@@ -615,8 +640,8 @@ inline void launch_wgrad_in(const HeadParams& p, hipStream_t st) {
     int grid = (int)((tiles + WNT / 64 - 1) / (WNT / 64));
     if (grid > G) grid = G;
     const size_t lds = ((size_t)9 * p.Cin + 1) * sizeof(float);
-    if (p.act == ACT_SIGMOID) hipLaunchKernelGGL(head_wgrad_in_kernel<ACT_SIGMOID>, dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
-    else hipLaunchKernelGGL(head_wgrad_in_kernel<0>, dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
+    if (p.act == ACT_SIGMOID) hipLaunchKernelGGL((head_wgrad_in_kernel<ACT_SIGMOID, DG>), dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
+    else hipLaunchKernelGGL((head_wgrad_in_kernel<0, DG>), dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
 }
 
 inline bool rows_form_ok(const HeadParams& p, int cout) {
@@ -662,6 +687,10 @@ int run(const HeadParams& p0, int op, hipStream_t st) {
     if (op == 0) {
         if (p.k == 3) hipLaunchKernelGGL((head_fwd_kernel<COUT, 3>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
         else hipLaunchKernelGGL((head_fwd_kernel<COUT, 1>), dim3((M + HNT - 1) / HNT), dim3(HNT), wbytes, st, p);
+    } else if (static const bool dg_in = [] { const char* e = getenv("DVS_HEAD_DGRAD_IN"); return !(e && e[0] == '0'); }();
+               op == 1 && COUT == 1 && p.k == 3 && p.pad == 1 && dg_in && rows_form_ok(p, COUT) && (p.act == 0 || p.act == ACT_SIGMOID) &&
+               (size_t)p.H * p.W * p.Cin * 4 < ((size_t)1 << 31)) {
+        launch_wgrad_in<true>(p, st);
     } else if (op == 1 && p.k == 3 && p.pad == 1 && COUT <= 2 && rows_form_ok(p, COUT) && p.H >= 3 && p.W >= 3) {
         const int segw = HNT / (p.Cin / 4), nseg = (p.W + segw - 1) / segw;
         const size_t lds = wbytes + (size_t)3 * (segw + 2) * COUT * sizeof(float);

@@ -41,6 +41,22 @@ for cin, H, W in ((16, 480, 640), (32, 240, 320), (64, 120, 160), (128, 60, 80))
     torch.cuda.synchronize()
     us = a.elapsed_time(e) / 20 * 1e3
     mb = (x.numel() + 2 * y.numel()) * 4 / 1e6
+    dx = torch.empty_like(x)
+
+    def bwd():
+        check(_lib.lib().dvs_conv2d_head_bwd_res(x.data_ptr(), w.data_ptr(), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                 C.byref(d), ACT["sigmoid"], None, _lib.stream()), "dvs_conv2d_head_bwd")
+    xr = x.clone().requires_grad_(True)
+    (gx,) = torch.autograd.grad(torch.sigmoid(F.conv2d(F.pad(xr, (1,) * 4, mode="reflect"), w, b)), [xr], dy)
+    for _ in range(3):
+        bwd()
+    a.record()
+    for _ in range(20):
+        bwd()
+    e.record()
+    torch.cuda.synchronize()
+    usb = a.elapsed_time(e) / 20 * 1e3
+    ex = float((dx - gx).abs().max() / gx.abs().max())
     yo = torch.empty_like(y)
 
     def fwd():
@@ -55,5 +71,5 @@ for cin, H, W in ((16, 480, 640), (32, 240, 320), (64, 120, 160), (128, 60, 80))
     torch.cuda.synchronize()
     usf = a.elapsed_time(e) / 20 * 1e3
     ef = float((yo - y).abs().max())
-    print("Cin %3d  %3dx%3d  wgrad %7.1f us  %6.1f MB  %5.2f TB/s   dw err %.1e  db err %.1e | fwd %7.1f us  %5.2f TB/s  err %.1e" % (
-        cin, H, W, us, mb, mb / us, ew, eb, usf, (x.numel() + y.numel()) * 4 / 1e6 / usf, ef))
+    print("Cin %3d  %3dx%3d  wgrad %7.1f us  %6.1f MB  %5.2f TB/s   dw err %.1e  db err %.1e | fwd %7.1f us  %5.2f TB/s  err %.1e | dgrad + wgrad %7.1f us  dx err %.1e" % (
+        cin, H, W, us, mb, mb / us, ew, eb, usf, (x.numel() + y.numel()) * 4 / 1e6 / usf, ef, usb, ex))
