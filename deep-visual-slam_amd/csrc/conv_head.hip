@@ -619,9 +619,83 @@ __global__ __launch_bounds__(WNT) void head_wgrad_in_kernel(HeadParams p, int R,
     if (p.dbias && threadIdx.x == 0) atomicAdd(p.dbias, sred[nw]);
 }
 
+// Forward of the one-channel 3x3 heads on the same walk: a wave owns 64 / (Cin/4) columns and walks down a run of rows with the 3x3
+// window of x in registers (nine 16-byte vectors per lane): a new output row costs THREE loads per lane (the row below, at the lane's
+// column and its two neighbours') instead of nine, padding is resolved in the addresses (reflection) or by masks (zeros); the
+// pixel's Cin/4 partial sums meet in a butterfly and chunk 0 stores bias + activation.
+constexpr int FNT = 256;       // (the window takes 60 registers more than the gradient kernels' state: three waves per SIMD as three four-wave workgroups per CU)
+template <int ACTF>
+__global__ __launch_bounds__(FNT) void head_fwd_walk_kernel(HeadParams p, int R, int n_rr, int n_cg) {
+    const int cpl = p.Cin >> 2, wpw = 64 / cpl;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane % cpl, slot = lane / cpl;
+    const int H = p.H, W = p.W, Cin = p.Cin;
+    const bool refl = p.reflect != 0;
+    f32x4 wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w + (size_t)t * Cin + kq * 4);
+    const float bias = p.bias ? p.bias[0] : 0.f;
+    const int ntile = p.B * n_rr * n_cg, nwave = gridDim.x * (FNT / 64);
+#pragma unroll 1
+    for (int tile = blockIdx.x * (FNT / 64) + wave; tile < ntile; tile += nwave) {
+        const int cg = tile % n_cg, rr = (tile / n_cg) % n_rr, b = tile / (n_cg * n_rr);
+        const int ix = cg * wpw + slot;
+        const bool col_ok = ix < W;
+        const int ixc = min(ix, W - 1);
+        // source columns of the taps kx = 0, 1, 2 and their masks (zero padding only: a reflected column always exists)
+        const int cl = refl ? reflect_i(ixc - 1, W) : max(ixc - 1, 0), cr = refl ? reflect_i(ixc + 1, W) : min(ixc + 1, W - 1);
+        const float ml = (refl || ixc >= 1) ? 1.f : 0.f, mr = (refl || ixc + 1 < W) ? 1.f : 0.f;
+        const size_t img = (size_t)b * H * W;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + img * Cin), 0, H * W * Cin * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y + img, 0, H * W * 4, 0x00020000);
+        const unsigned ol = (unsigned)(cl * Cin + kq * 4) * 4u, oc = (unsigned)(ixc * Cin + kq * 4) * 4u, orr = (unsigned)(cr * Cin + kq * 4) * 4u;
+        const int xrow_b = W * Cin * 4, yrow_b = W * 4;
+        struct Row { f32x4 v[3]; };
+        // x row sy at my three columns; sy is the padded row: reflected into the image, or (zero padding) clamped and masked at use
+        auto rload = [&](int sy, Row& o) {
+            const int r = refl ? reflect_i(min(max(sy, -1), H), H) : min(max(sy, 0), H - 1);
+            o.v[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, ol, r * xrow_b, 0));
+            o.v[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, oc, r * xrow_b, 0));
+            o.v[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, orr, r * xrow_b, 0));
+        };
+        auto rowmask = [&](int sy) { return (refl || (sy >= 0 && sy < H)) ? 1.f : 0.f; };
+        const int oy0 = rr * R, oy1 = min(oy0 + R, H);
+        Row top, mid, rq[PF];
+        rload(oy0 - 1, top);
+        rload(oy0, mid);
+        float mt = rowmask(oy0 - 1);                      // mask of the window's top row (the middle row always exists)
+#pragma unroll
+        for (int k = 0; k < PF; ++k) rload(oy0 + 1 + k, rq[k]);
+#pragma unroll 1
+        for (int oyg = oy0; oyg < oy1; oyg += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int oy = oyg + k;
+                const Row bot = rq[k];
+                const float mb = rowmask(oy + 1);
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                // taps (ky, kx): rows top / mid / bot, columns left / centre / right; column masks ride on the weights' side
+                a += (top.v[0] * wv[0] * ml + top.v[1] * wv[1] + top.v[2] * wv[2] * mr) * mt;
+                a += mid.v[0] * wv[3] * ml + mid.v[1] * wv[4] + mid.v[2] * wv[5] * mr;
+                a += (bot.v[0] * wv[6] * ml + bot.v[1] * wv[7] + bot.v[2] * wv[8] * mr) * mb;
+                float sum = (a[0] + a[1]) + (a[2] + a[3]);
+                for (int off = cpl >> 1; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                const float yv = apply_act(sum + bias, ACTF);
+                const unsigned so = (oy < oy1 && col_ok && kq == 0) ? (unsigned)ixc * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yr, so, min(oy, H - 1) * yrow_b, 0);
+                top = mid;
+                mid = bot;
+                mt = 1.f;
+                rload(oy + 1 + PF, rq[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 // One workgroup per CU (fewer measured slower at every scale: tools/head_bench.py with DVS_HEAD_WGRAD_WGS); rows per wave tile: the run
 // length in [8, 32] with the cheapest schedule -- rounds of the persistent waves x (R + about half a step of extra g rows).
-template <bool DG = false>
+template <bool DG = false, bool FWD = false>
 inline void launch_wgrad_in(const HeadParams& p, hipStream_t st) {
     static const int forced = [] { const char* e = getenv("DVS_HEAD_WGRAD_WGS"); return e ? atoi(e) : 0; }();
     const int cpl = p.Cin / 4, wpw = 64 / cpl, n_cg = (p.W + wpw - 1) / wpw;
@@ -640,6 +714,13 @@ inline void launch_wgrad_in(const HeadParams& p, hipStream_t st) {
     int grid = (int)((tiles + WNT / 64 - 1) / (WNT / 64));
     if (grid > G) grid = G;
     const size_t lds = ((size_t)9 * p.Cin + 1) * sizeof(float);
+    if constexpr (FWD) {
+        int fgrid = (int)((tiles + FNT / 64 - 1) / (FNT / 64));
+        if (fgrid > 3 * G) fgrid = 3 * G;
+        if (p.act == ACT_SIGMOID) hipLaunchKernelGGL(head_fwd_walk_kernel<ACT_SIGMOID>, dim3(fgrid), dim3(FNT), 0, st, p, bestR, n_rr, n_cg);
+        else hipLaunchKernelGGL(head_fwd_walk_kernel<ACT_NONE>, dim3(fgrid), dim3(FNT), 0, st, p, bestR, n_rr, n_cg);
+        return;
+    }
     if (p.act == ACT_SIGMOID) hipLaunchKernelGGL((head_wgrad_in_kernel<ACT_SIGMOID, DG>), dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
     else hipLaunchKernelGGL((head_wgrad_in_kernel<0, DG>), dim3(grid), dim3(WNT), lds, st, p, bestR, n_rr, n_cg);
 }
@@ -677,9 +758,11 @@ int run(const HeadParams& p0, int op, hipStream_t st) {
     const size_t wbytes = (size_t)COUT * Ktot * sizeof(float);
     if (op != 1 && rows_form_ok(p, COUT)) {
         static const bool in_form = [] { const char* e = getenv("DVS_HEAD_WGRAD_IN"); return !(e && e[0] == '0'); }();
-        if (op == 2 && COUT == 1 && p.k == 3 && p.pad == 1 && in_form && (p.act == 0 || p.act == ACT_SIGMOID) &&
-            (size_t)p.H * p.W * p.Cin * 4 < ((size_t)1 << 31))
-            launch_wgrad_in(p, st);
+        static const bool fwd_walk = [] { const char* e = getenv("DVS_HEAD_FWD_WALK"); return !(e && e[0] == '0'); }();
+        const bool walk_ok = COUT == 1 && p.k == 3 && p.pad == 1 && (p.act == ACT_NONE || p.act == ACT_SIGMOID) &&
+                             (size_t)p.H * p.W * p.Cin * 4 < ((size_t)1 << 31);
+        if (op == 2 && walk_ok && in_form) launch_wgrad_in(p, st);
+        else if (op == 0 && walk_ok && fwd_walk && (!p.reflect || (p.H >= 2 && p.W >= 2))) launch_wgrad_in<false, true>(p, st);
         else if (p.k == 3) launch_rows<COUT, 3>(p, op, st);
         else launch_rows<COUT, 1>(p, op, st);
         return DVS_OK;
