@@ -1,4 +1,11 @@
 #!/bin/bash
+# Per-launch table of one single-stream step on the GPU box (tools/per_launch.py) -> gpurun_out/per_launch_fp32.txt; with variant builds
+# (tools/build_variant.py <name> --flag=-DTHIN_DBG=<bits> --only=conv_thin.hip ...) as arguments, one table per variant beside it:
+#   gpurun -- bash tools/run_pl.sh [variant ...]
 cd /root/repo
-echo default; timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_fp32.txt 2>&1; grep -n "^== conv_dgrad" -A66 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(24|25|26)  work"
-for v in 1 2 16 5 13 29; do echo "THIN_DBG $v"; DVS_LIB=/root/repo/deep-visual-slam_amd/csrc/build/variant_tdbg$v.so timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_tdbg.txt 2>&1; grep -n "^== conv_dgrad" -A66 gpurun_out/per_launch_tdbg.txt | grep -E "^[0-9]+-\s+(24|25|26)  work"; done
+timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_fp32.txt 2>&1; echo "default rc=$?"
+grep "^== " gpurun_out/per_launch_fp32.txt
+for v in "$@"; do
+    DVS_LIB=/root/repo/deep-visual-slam_amd/csrc/build/variant_$v.so timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_$v.txt 2>&1; echo "$v rc=$?"
+    grep "^== " gpurun_out/per_launch_$v.txt
+done
