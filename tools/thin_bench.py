@@ -1,4 +1,6 @@
-"""Weight-gradient timing of the decoder's thin layers in their real gather modes (DVS_CONV_THIN=0 for the generic kernel)."""
+"""Weight-gradient timing of the decoder's thin layers in their real gather modes (DVS_CONV_THIN=0 for the generic kernel).
+Wall-clock over back-to-back Python calls: below ~120 us per call the figure is the HOST loop, not the kernel -- use tools/per_launch.py
+(events around the launch inside a real step) for those, as DESIGN.md section 11-2b does."""
 import sys, json, time
 import torch
 sys.path.insert(0, ".")
