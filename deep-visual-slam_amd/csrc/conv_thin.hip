@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
 #else
     constexpr int NS = 2;                                // (three and four sets measured the same; they cost a workgroup per CU)
 #endif
-    f32x4 rx[NS][X_LOADS];
+    f32x4 rx[NS > 3 ? NS : 3][X_LOADS];                  // (three sets for the prologue's three rows; the loop uses the first NS)
     auto load_row = [&](int pr, auto set) {              // padded row pr = source row refl(pr - 1)
         constexpr int S = decltype(set)::value;
         const int sr = reflect_i(min(pr, p.H + 1) - 1, p.H);
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(NT) void thin_wgrad_kernel(ThinParams p) {
 
     using S0 = std::integral_constant<int, 0>;
     if (oy_begin < oy_end) {
-        for (int pr = oy_begin; pr < oy_begin + 3; ++pr) {
-            load_row(pr, S0{});
-            store_row(pr, S0{});
-        }
+        // the three rows of the first window and the first dY row: all loads first (one HBM round trip instead of four -- every
+        // workgroup of the one resident round is here at the same time, so nothing else covers it)
+        static_for_thin<0, 3>([&](auto k) { load_row(oy_begin + k.value, k); });
         load_d(oy_begin, S0{});
+        static_for_thin<0, 3>([&](auto k) { store_row(oy_begin + k.value, k); });
         store_d(0, S0{});
         static_for_thin<0, NS - 1>([&](auto k) {          // set k: the row stage oy_begin + k stores
             load_row(oy_begin + 3 + k.value, k);
@@ -391,22 +391,24 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(ThinFwdParams p) {
         x_loff[j] = px * CS + c;
     }
     f32x4 rx[X_LOADS];
-    auto load_row = [&](int pr) {
+    auto load_row_to = [&](int pr, f32x4 (&r)[X_LOADS]) {
         const int sr = reflect_i(pr - 1, p.H);
         const float* r1 = p.x + ((size_t)b * H1 + (p.up ? sr >> 1 : sr)) * W1 * CIN;
 #pragma unroll
-        for (int j = 0; j < X_LOADS; ++j) rx[j] = *reinterpret_cast<const f32x4*>(r1 + x_goff[j]);
+        for (int j = 0; j < X_LOADS; ++j) r[j] = *reinterpret_cast<const f32x4*>(r1 + x_goff[j]);
     };
-    auto store_row = [&](int pr) {
+    auto store_row_from = [&](int pr, const f32x4 (&r)[X_LOADS]) {
         float* dst = Ps + (pr & 3) * ROWF;
 #pragma unroll
         for (int j = 0; j < X_LOADS; ++j)
             if (x_ok[j]) {                               // CS is even, not a multiple of 4: two 8-byte stores
                 float2* d2 = reinterpret_cast<float2*>(dst + x_loff[j]);
-                d2[0] = float2{rx[j][0], rx[j][1]};
-                d2[1] = float2{rx[j][2], rx[j][3]};
+                d2[0] = float2{r[j][0], r[j][1]};
+                d2[1] = float2{r[j][2], r[j][3]};
             }
     };
+    auto load_row = [&](int pr) { load_row_to(pr, rx); };
+    auto store_row = [&](int pr) { store_row_from(pr, rx); };
 
     // B operand: lane (n = lane & 15, kidx = lane >> 4) holds W[n][tap][4 c4 + kidx] for every k-step (tap, c4)
     const int n = lane & 15, kidx = lane >> 4;
@@ -417,10 +419,15 @@ __global__ __launch_bounds__(NT) void thin_fwd_kernel(ThinFwdParams p) {
     const int a_lane = (wave * PXW + n) * CS + kidx;     // pixel lane & 15 of my first tile, channel kidx
 
     if (oy_begin < oy_end) {
-        for (int pr = oy_begin; pr < oy_begin + 3; ++pr) {
-            load_row(pr);
-            store_row(pr);
-        }
+        // the three rows of the first window: all loads first (one HBM round trip, not three -- every workgroup of the one resident
+        // round starts here at the same time, so nothing else covers it)
+        f32x4 r0[X_LOADS], r1[X_LOADS];
+        load_row_to(oy_begin, r0);
+        load_row_to(oy_begin + 1, r1);
+        load_row(oy_begin + 2);
+        store_row_from(oy_begin, r0);
+        store_row_from(oy_begin + 1, r1);
+        store_row(oy_begin + 2);
     }
     __syncthreads();
 #pragma unroll 1
@@ -542,7 +549,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
     // only for the one-wave-per-SIMD form (upconv_1_1): the others hide the round trip behind their second and third workgroup, and
     // the second copy of the stage costs them one
     constexpr int NS = (NTN == 3) ? 2 : 1;
-    f32x4 rd[NS][X_LOADS], ry[NS][X_LOADS];
+    f32x4 rd[3][X_LOADS], ry[3][X_LOADS];                // (three sets for the prologue's three rows; the loop uses the first NS)
     const bool elu = p.dact == ACT_ELU;
     auto load_row = [&](int d, auto set) {                // dZ row d (may be -1 or H: zeros)
         constexpr int S = decltype(set)::value;
@@ -600,10 +607,8 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
 
     using S0 = std::integral_constant<int, 0>;
     if (iy_begin < iy_end) {
-        for (int d = iy_begin - 1; d <= iy_begin + 1; ++d) {
-            load_row(d, S0{});
-            store_row(d, S0{});
-        }
+        static_for_thin<0, 3>([&](auto k) { load_row(iy_begin - 1 + k.value, k); });           // one round trip for the first window
+        static_for_thin<0, 3>([&](auto k) { store_row(iy_begin - 1 + k.value, k); });
         static_for_thin<0, NS - 1>([&](auto k) { load_row(iy_begin + 2 + k.value, k); });      // set k: the row stage iy_begin + k stores
     }
     __syncthreads();

@@ -1,5 +1,9 @@
 #!/bin/bash
-# Thin decoder layers: weight-gradient bench + the convolution tests (gpurun_out/)
+# Thin decoder layers: per-launch table of a step (the thin kernels are launches 35 / 40 of the forward slot, 24-26 of the data-gradient
+# slot, 23 / 24 of the weight-gradient slot at batch 12) + the convolution and full-size tests (gpurun_out/)
 cd /root/repo
-timeout -k 10 300 python tools/thin_bench.py 12 2>&1 | grep name
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py -x -q > gpurun_out/t_thin.log 2>&1; echo rc=$?; tail -3 gpurun_out/t_thin.log
+timeout -k 10 600 python tools/per_launch.py 12 4 4 > gpurun_out/per_launch_fp32.txt 2>&1; echo rc=$?
+grep -n "^== conv_fwd" -A42 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(35|40)  work"
+grep -n "^== conv_dgrad" -A66 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(24|25|26)  work"
+grep -n "^== conv_wgrad" -A54 gpurun_out/per_launch_fp32.txt | grep -E "^[0-9]+-\s+(23|24)  work"
+timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_fullsize_gpu.py -x -q > gpurun_out/t_thin.log 2>&1; echo rc=$?; tail -3 gpurun_out/t_thin.log
