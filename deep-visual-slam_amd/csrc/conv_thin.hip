@@ -592,9 +592,13 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
     const int a_lane = (wave * PXW + n) * CS + kidx;       // + (16 t + 2 - kx) CS: entry of pixel (lane & 15) of tile t, tap kx
     // column fold: the one lane whose pixel is image column 1 (first segment, wave 0, tile 0) / W - 2 (last segment, last
     // wave, last tile) reads entry 1 (column 0) / SEG (column W - 1); the other lanes of that tile read the zero halo entry
-    const bool edge_l = seg == 0 && wave == 0, edge_r = seg == p.nseg - 1 && wave == 3;
+    // the last segment may be narrower than SEG (W a multiple of 16 only: upconv_1_0's 160 columns = 64 + 64 + 32): its columns past
+    // the image are staged as zeros, the waves past them store nothing, and the right-hand fold moves to the wave that owns column W - 1
+    const int wseg = min(SEG, p.W - x0);
+    const bool edge_l = seg == 0 && wave == 0, edge_r = seg == p.nseg - 1 && wave == wseg / PXW - 1;
+    const bool wave_live = wave * PXW < wseg;
     const int fold_l = ((n == 1) ? 1 : 0) * CS + kidx;
-    const int fold_r = ((n == 14) ? SEG : SEG + 1) * CS + kidx;
+    const int fold_r = ((n == 14) ? wseg : wseg + 1) * CS + kidx;
 
     f32x4 acc[PT][NTN];
     auto zero_acc = [&]() {
@@ -677,7 +681,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
             taps(row, 2);
         }
         // C/D map: pixel = 4 (lane >> 4) + r, channel = lane & 15
-        if (any_coarse && (iy & 1) && !(THIN_DBG & 16)) { // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
+        if (any_coarse && (iy & 1) && wave_live && !(THIN_DBG & 16)) { // rows iy - 1 and iy are in the accumulators: 2x2 sums, one coarse row
             float* orow = p.dx + (((size_t)b * (p.H >> 1) + (iy >> 1)) * (p.W >> 1) + ((x0 + wave * PXW + 4 * kidx) >> 1)) * p.C1 +
                           n_base + n;
 #pragma unroll
@@ -691,7 +695,7 @@ __device__ __forceinline__ void thin_dgrad_body(const ThinDgradParams& p) {
                     }
                 }
         }
-        if (any_direct && !(THIN_DBG & 16)) {
+        if (any_direct && wave_live && !(THIN_DBG & 16)) {
             const int cs = p.nout - p.C1;                 // channels of the tensor these tiles belong to (C1 == 0: the input itself)
             float* base = p.C1 > 0 ? p.dx_skip : p.dx;
             float* orow = base + (((size_t)b * p.H + iy) * p.W + x0 + wave * PXW + 4 * kidx) * cs + (n_base - p.C1) + n;
@@ -730,7 +734,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 template <int CK, int NTN, int SEG, bool W1 = false>
 void launch_thin_dgrad(ThinDgradParams p, hipStream_t st) {
     auto kern = W1 ? thin_dgrad_kernel_w1<CK, NTN, SEG> : thin_dgrad_kernel<CK, NTN, SEG>;
-    p.nseg = p.W / SEG;
+    p.nseg = (p.W + SEG - 1) / SEG;
     p.nsplit = p.nout / (16 * NTN);
     static const int slots = [] {
         int occ = 0, dev = 0, cus = 256;
@@ -816,7 +820,8 @@ bool thin_dgrad(const float* dy, const float* wt, float* dx, const float* y_out,
     else if (Cout == 16 && Cin == 32 && split_c1 == 0 && W % 64 == 0) launch_thin_dgrad<16, 2, 64>(p, st);          // upconv_0_0
     else if (Cout == 32 && Cin % 48 == 0 && Cin <= 192 && split_c1 % 16 == 0 && W % 64 == 0)
         launch_thin_dgrad<32, 3, 64, true>(p, st);   // upconv_1_1 (the two-tile form at two workgroups per CU: 696 against 565 us)
-    else if (Cout == 32 && Cin % 32 == 0 && Cin <= 128 && split_c1 % 16 == 0 && W % 64 == 0) launch_thin_dgrad<32, 2, 64>(p, st);
+    else if (Cout == 32 && Cin % 32 == 0 && Cin <= 128 && split_c1 % 16 == 0 && (W % 64 == 0 || (W % 16 == 0 && W > 64)))
+        launch_thin_dgrad<32, 2, 64>(p, st);          // (upconv_1_0: 160 columns, a ragged last segment)
     else return false;
     return true;
 }
